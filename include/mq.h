@@ -1,0 +1,200 @@
+/*
+ * mq.h -- C ABI of libmqhip.so: the MI355X-native (HIP / gfx950) replacement for merian-quake's
+ * `GBuffer` + `Renderer (MCPG)` render nodes.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Every entry point cites the reference
+ * interface it stands in for (file:line relative to the merian-quake tree).  INTEGRATION.md shows
+ * the merian `Node` subclass a maintainer would write on top of this header.
+ *
+ * Conventions:
+ *  - every call returns 0 on success or a negative MQ_E* code; mq_last_error() has the text;
+ *  - a context is single-caller (merian calls process() from the main thread only,
+ *    src/merian-quake.cpp:272-275); calls are asynchronous w.r.t. the device unless stated;
+ *  - scene upload calls copy; the caller keeps ownership of its arrays;
+ *  - output pointers stay valid until the next mq_connect()/mq_destroy();
+ *  - there is NO CPU fallback: every device entry point fails with MQ_ENODEVICE without a GPU.
+ */
+#ifndef MQ_H
+#define MQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MQ_ABI_VERSION 1
+
+enum {
+    MQ_OK = 0,
+    MQ_EINVAL = -1,    /* bad argument */
+    MQ_ENODEVICE = -2, /* no HIP device / host-only context */
+    MQ_EHIP = -3,      /* a HIP call failed */
+    MQ_ESTATE = -4,    /* call sequence error (e.g. process before connect) */
+    MQ_ENOMEM = -5,
+    MQ_EIO = -6,       /* file could not be read / parsed */
+    MQ_EUNKNOWN_KEY = -7
+};
+
+/* res/shader/config.h:5-6 */
+#define MQ_MAX_GLTEXTURES 4096
+#define MQ_MAX_GEOMETRIES 16
+
+/* VertexExtraData, src/game/quake_helpers.hpp:10-34 (28 bytes, one per triangle) */
+typedef struct mq_ext {
+    uint16_t texnum_alpha;
+    uint16_t texnum_fb_flags;
+    uint32_t n0_gloss_norm;
+    uint32_t n1_brush;
+    uint32_t n2;
+    uint16_t st[6];
+} mq_ext;
+
+/* UniformData push constant, res/shader/scene_info.glsl.h:18-32 == src/game/quake_node.hpp:42-60
+ * (124 bytes) */
+typedef struct mq_uniform {
+    float cam_x[4];      /* xyz camera position, w = fog mu_t */
+    float cam_w[4];      /* xyz forward, w = time diff (1 if paused) */
+    float cam_u[4];      /* xyz up */
+    float prev_cam_x[4]; /* w = mu_s.r */
+    float prev_cam_w[4]; /* w = mu_s.g */
+    float prev_cam_u[4]; /* w = mu_s.b */
+    uint32_t sky_rt_bk, sky_lf_ft, sky_up_dn;
+    float cl_time;
+    uint32_t frame;
+    uint32_t player;
+    uint32_t rt_config;
+} mq_uniform;
+
+/* QuakeNode::ConstantData, src/game/quake_node.hpp:62-69 */
+typedef struct mq_constants {
+    float sun_color[3];
+    float sun_direction[3];
+    float fov;
+    float fov_tan_alpha_half;
+    float volume_max_t;
+} mq_constants;
+
+/* geometry flags: instance flags of src/game/quake_node.cpp:869-871,891-892 */
+enum { MQ_GEO_OPAQUE = 1, MQ_GEO_STATIC = 2 };
+/* texture flags: src/game/quake_node.hpp:86-108 (sRGB unless *_norm/_gloss), sampler choice */
+enum { MQ_TEX_SRGB = 1, MQ_TEX_LINEAR = 2 };
+
+/* named outputs of the two nodes: src/render_mcpg/render_mcpg.cpp:42-52, src/gbuffer/gbuffer.cpp:27-43 */
+enum {
+    MQ_OUT_IRRADIANCE = 0,    /* "irradiance" RGBA32F: rgb mean radiance, a = luminance 2nd moment */
+    MQ_OUT_GB_ALBEDO = 1,     /* gbuffer "albedo" RGBA16F */
+    MQ_OUT_GB_IRRADIANCE = 2, /* gbuffer "irradiance" RGBA16F (first-hit emission) */
+    MQ_OUT_GB_MV = 3,         /* gbuffer "mv" RG16F */
+    MQ_OUT_GBUFFER = 4,       /* gbuffer "gbuffer": 16 B/pixel */
+    MQ_OUT_HITS = 5,          /* gbuffer "hits": 40 B/pixel CompressedHit, res/shader/hit.glsl.h:19-30 */
+    MQ_OUT_TILES = 6,         /* this rank's irradiance tiles, tile-major (multi-GPU exchange buffer) */
+    MQ_OUT_COUNT
+};
+
+typedef struct mq_io_desc {
+    uint32_t width, height;
+    size_t bytes[MQ_OUT_COUNT];          /* size of each output buffer */
+    uint32_t bytes_per_pixel[MQ_OUT_COUNT];
+    size_t state_bytes_markovchain, state_bytes_lightcache, state_bytes_update_queue;
+} mq_io_desc;
+
+/* work counters of the last MQ_COUNT-enabled frame (algorithmic-bytes inputs) */
+typedef struct mq_counters {
+    uint64_t rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
+        mc_updates_dropped, mc_state_reads, pixels;
+} mq_counters;
+
+typedef struct mq_ctx mq_ctx;
+
+/* ---- lifecycle ---- */
+/* device >= 0: HIP device ordinal.  device < 0: host-only context (scene, BVH, properties; every
+ * device call returns MQ_ENODEVICE). */
+int mq_create(mq_ctx** out, int device);
+void mq_destroy(mq_ctx* ctx);
+const char* mq_last_error(const mq_ctx* ctx);
+int mq_abi_version(void);
+
+/* ---- properties(): src/render_mcpg/render_mcpg.cpp:419-578, src/gbuffer/gbuffer.cpp (hide sun) --
+ * Keys are the reference's own strings ("BSDF Prob", "mc samples", "adaptive grid buf size",
+ * "LC grid type", "reference mode", "seed", ...; full list: mq_property_name()).  Options
+ * ("adaptive grid type", "LC grid type", "debug output") take the option index or its string via
+ * mq_set_property_str.  Returns 1 if the change needs a reconnect (NEEDS_RECONNECT,
+ * render_mcpg.cpp:567-575), 0 if it only refreshes the kernel parameter block. */
+int mq_set_property(mq_ctx* ctx, const char* key, double value);
+int mq_set_property_str(mq_ctx* ctx, const char* key, const char* value);
+int mq_get_property(const mq_ctx* ctx, const char* key, double* value);
+int mq_property_count(void);
+const char* mq_property_name(int index);
+/* load the "properties" object of a node from a merian-quake graph JSON (res/default_config.json
+ * layout): node_name e.g. "render_markovchain" or "gbuffer". */
+int mq_load_properties_json(mq_ctx* ctx, const char* json_text, const char* node_name);
+void mq_properties_header_defaults(mq_ctx* ctx); /* src/render_mcpg/render_mcpg.hpp:108-166 */
+void mq_properties_json_defaults(mq_ctx* ctx);   /* res/default_config.json:599-638 */
+
+/* ---- scene inputs: connectors vtx/prev_vtx/idx/ext/textures/tlas, render_mcpg.hpp:61-70 ---- */
+int mq_scene_set_geometry(mq_ctx* ctx, int slot, const float* vtx, const float* prev_vtx,
+                          uint32_t n_vtx, const uint32_t* idx, const mq_ext* ext, uint32_t n_tri,
+                          uint32_t flags);
+int mq_scene_set_texture(mq_ctx* ctx, uint32_t texnum, uint32_t w, uint32_t h,
+                         const uint8_t* rgba8, uint32_t flags);
+/* (re)builds the compressed wide BVH and uploads; stands in for merian's "Acceleration Structure
+ * Builder" node fed by tlas_info (res/default_config.json:3-20,400-403). */
+int mq_scene_commit(mq_ctx* ctx);
+/* QuakeRenderInfo::constant + constant_data_update, src/game/quake_node.hpp:62-84 */
+int mq_set_constants(mq_ctx* ctx, const mq_constants* c);
+int mq_get_constants(const mq_ctx* ctx, mq_constants* out);
+/* read back what the context holds (host copies) */
+int mq_scene_get_geometry(const mq_ctx* ctx, int slot, const float** vtx, const float** prev_vtx,
+                          uint32_t* n_vtx, const uint32_t** idx, const mq_ext** ext, uint32_t* n_tri,
+                          uint32_t* flags);
+int mq_scene_get_texture(const mq_ctx* ctx, uint32_t texnum, uint32_t* w, uint32_t* h,
+                         const uint8_t** rgba8, uint32_t* flags);
+int mq_scene_stats(const mq_ctx* ctx, uint64_t* n_tris, uint64_t* n_nodes, uint64_t* bvh_bytes,
+                   float* sah_cost);
+
+/* ---- describe_outputs / on_connected / process: render_mcpg.cpp:36-115,117-320 ---- */
+int mq_describe(const mq_ctx* ctx, uint32_t width, uint32_t height, mq_io_desc* out);
+int mq_connect(mq_ctx* ctx, uint32_t width, uint32_t height);
+/* one frame on `stream` (a hipStream_t, NULL = default stream).  render == 0 runs the clear pass
+ * (render_mcpg.cpp:243-250).  Iteration 0 zero-fills all learning state (render_mcpg.cpp:221-226). */
+int mq_process(mq_ctx* ctx, const mq_uniform* u, int render, void* stream);
+int mq_sync(mq_ctx* ctx);
+int mq_map_output(mq_ctx* ctx, int which, void** dev_ptr, size_t* bytes);
+int mq_read_output(mq_ctx* ctx, int which, void* host_dst, size_t bytes); /* sync + D2H copy */
+/* device time of the last frame's hot-path kernels (hipEvent pair on the process stream) */
+int mq_last_frame_ms(mq_ctx* ctx, float* total_ms, float* render_ms, float* update_ms);
+/* enable work counting for subsequent frames (separate kernel instantiation, slower) */
+int mq_enable_counters(mq_ctx* ctx, int on);
+int mq_get_counters(mq_ctx* ctx, mq_counters* out);
+int mq_reset_state(mq_ctx* ctx); /* next process() behaves like iteration 0 */
+
+/* ---- multi-GPU framebuffer sharding (no reference counterpart) ----
+ * Rank r of `world` renders the 8x8-pixel tiles t with t % world == r into MQ_OUT_TILES
+ * (tile-major, 64 RGBA32F pixels per tile).  After an all-gather of the per-rank buffers (done by
+ * the caller, e.g. RCCL through torch.distributed), mq_untile() scatters the gathered buffer
+ * (rank-major) into the full MQ_OUT_IRRADIANCE image. */
+int mq_set_partition(mq_ctx* ctx, int rank, int world);
+int mq_tiles_per_rank(const mq_ctx* ctx, uint32_t* tiles, size_t* bytes);
+int mq_untile(mq_ctx* ctx, const void* gathered_dev, void* stream);
+
+/* ---- closest-hit ray queries against the committed scene (raytrace.glsl:82-119 semantics) ---- */
+int mq_trace_rays(mq_ctx* ctx, const float* org_host, const float* dir_host, uint32_t n,
+                  uint32_t* prim_host, float* t_host, float* uv_host);
+/* device-side evaluation of the shading primitives, for known-answer tests against the oracle */
+int mq_math_eval(mq_ctx* ctx, int op, const float* in_host, float* out_host, uint32_t n);
+
+/* ---- scene sources ---- */
+/* seeded synthetic "BSP-like" scenes: "synth_start", "synth_sepulcher", "synth_tears",
+ * "synth_azad" (SURVEY 8d).  Fills geometry slots, textures, constants. */
+int mq_synth_scene(mq_ctx* ctx, const char* name, uint32_t seed);
+/* deterministic fly-through camera for a synthetic scene: fills a uniform for frame index f */
+int mq_synth_camera(const mq_ctx* ctx, uint32_t frame, mq_uniform* out);
+/* Quake BSP29 / BSP2 world model + palette (768-byte file or NULL for a built-in grey ramp) */
+int mq_load_bsp(mq_ctx* ctx, const char* bsp_path, const char* palette_path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MQ_H */

@@ -1,0 +1,794 @@
+// mq_api.cpp -- implementation of the C ABI in include/mq.h: the HIP-stream render node that
+// stands in for merian-quake's GBuffer + RendererMarkovChain nodes.
+//
+//   describe / connect   src/render_mcpg/render_mcpg.cpp:36-115, src/gbuffer/gbuffer.cpp:23-66
+//   process              src/render_mcpg/render_mcpg.cpp:117-320, src/gbuffer/gbuffer.cpp:68-128
+//   properties           src/render_mcpg/render_mcpg.cpp:419-578
+//
+// There is no CPU rendering path in this library: without a HIP device every device entry point
+// returns MQ_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "mq_host.h"
+
+// launchers implemented in mq_kernels.hip
+int mq_launch_render(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s);
+int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+int mq_launch_clear(const MqFrame& F, hipStream_t s);
+int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
+int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s);
+int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int no, const float* in, float* out, uint32_t n, hipStream_t s);
+int mq_render_block_size();
+int mq_spill_entries();
+int mq_render_blocks_per_cu(bool guided, bool count);
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+};
+
+struct mq_ctx {
+    int device = -1;
+    std::string err;
+    MqProps props;
+    mq_constants constants{};
+    MqHostGeo geo[MQ_MAX_GEOMETRIES];
+    std::vector<MqHostTex> tex;
+    MqSynthInfo synth;
+    // committed scene (host copies kept for stats / debugging)
+    std::vector<MqNode> nodes;
+    std::vector<MqTri> tris;
+    float sah_cost = 0.0f;
+    bool committed = false;
+    // device scene
+    DevBuf d_nodes, d_tris, d_texdesc, d_texels, d_lut;
+    DevBuf d_ext[MQ_MAX_GEOMETRIES], d_idx[MQ_MAX_GEOMETRIES], d_prev[MQ_MAX_GEOMETRIES];
+    MqSceneDev scene{};
+    // frame state
+    bool connected = false;
+    uint32_t W = 0, H = 0, tiles_x = 0, tiles_y = 0;
+    int rank = 0, world = 1;
+    uint32_t n_local_tiles = 0, tiles_per_rank = 0;
+    DevBuf d_out[MQ_OUT_COUNT];
+    DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
+    uint32_t queue_cap = 0;
+    uint32_t mc_total = 0, lc_total = 0;
+    uint64_t iteration = 0;
+    bool params_dirty = true;
+    MqParams params{};
+    bool count_enabled = false;
+    int cu_count = 0, grid_blocks = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    hipStream_t last_stream = nullptr;
+    mq_ctx() : tex(MQ_MAX_GLTEXTURES) {}
+};
+
+MqHostGeo& mq_ctx_geo(mq_ctx* c, int slot) { return c->geo[slot]; }
+MqHostTex& mq_ctx_tex(mq_ctx* c, uint32_t t) { return c->tex[t]; }
+mq_constants& mq_ctx_constants(mq_ctx* c) { return c->constants; }
+MqSynthInfo& mq_ctx_synth(mq_ctx* c) { return c->synth; }
+void mq_ctx_clear_scene(mq_ctx* c) {
+    for (auto& g : c->geo) g = MqHostGeo();
+    for (auto& t : c->tex) t = MqHostTex();
+    c->synth = MqSynthInfo();
+    c->committed = false;
+}
+
+namespace {
+
+int fail(mq_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), MQ_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+void dev_free(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+int dev_alloc(mq_ctx* c, DevBuf& b, size_t bytes) {
+    dev_free(b);
+    if (bytes == 0) bytes = 16;
+    HIPCHK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return MQ_OK;
+}
+int dev_upload(mq_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    int r = dev_alloc(c, b, bytes);
+    if (r) return r;
+    if (bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return MQ_OK;
+}
+
+// ---- property table: the reference's key strings (render_mcpg.cpp:449-548, gbuffer.cpp) ---------
+enum PType { PT_BOOL, PT_INT, PT_UINT, PT_FLOAT, PT_OPTION };
+struct PropDesc { const char* key; PType type; size_t off; bool reconnect; const char* options[10]; };
+#define POFF(f) offsetof(MqProps, f)
+const PropDesc k_props[] = {
+    {"randomize seed", PT_BOOL, POFF(randomize_seed), false, {}},
+    {"seed", PT_UINT, POFF(seed), false, {}},
+    {"reference mode", PT_BOOL, POFF(reference_mode), true, {}},
+    {"ML Prior", PT_FLOAT, POFF(dir_guide_prior), false, {}},
+    {"mc samples", PT_INT, POFF(mc_samples), false, {}},
+    {"adaptive grid prob", PT_FLOAT, POFF(mc_samples_adaptive_prob), false, {}},
+    {"adaptive grid type", PT_OPTION, POFF(mc_adaptive_grid_type), true, {"exponential", "quadratic"}},
+    {"adaptive grid buf size", PT_UINT, POFF(mc_adaptive_buffer_size), true, {}},
+    {"adaptive grid tan(alpha/2)", PT_FLOAT, POFF(mc_adaptive_grid_tan_alpha_half), false, {}},
+    {"adaptive grid steps per unit", PT_FLOAT, POFF(mc_adaptive_grid_steps_per_unit_size), false, {}},
+    {"adaptive grid min width", PT_FLOAT, POFF(mc_adaptive_grid_min_width), false, {}},
+    {"adaptive grid power", PT_FLOAT, POFF(mc_adaptive_grid_power), false, {}},
+    {"static grid buf size", PT_UINT, POFF(mc_static_buffer_size), true, {}},
+    {"mc static width", PT_FLOAT, POFF(mc_static_grid_width), true, {}},
+    {"mc fast recovery", PT_BOOL, POFF(mc_fast_recovery), false, {}},
+    {"spp", PT_INT, POFF(spp), false, {}},
+    {"max path length", PT_INT, POFF(max_path_length), false, {}},
+    {"BSDF Prob", PT_FLOAT, POFF(surf_bsdf_p), false, {}},
+    {"volume spp", PT_INT, POFF(volume_spp), false, {}},
+    {"dist mc samples", PT_INT, POFF(distance_mc_samples), false, {}},
+    {"dist mc grid width", PT_INT, POFF(distance_mc_grid_width), true, {}},
+    {"dist mc states per vertex", PT_UINT, POFF(distance_mc_vertex_state_count), true, {}},
+    {"particle size", PT_FLOAT, POFF(volume_particle_size_um), false, {}},
+    {"dist guide p", PT_FLOAT, POFF(dist_guide_p), false, {}},
+    {"Phase Prob", PT_FLOAT, POFF(volume_phase_p), false, {}},
+    {"volume forward project", PT_BOOL, POFF(volume_forward_project), false, {}},
+    {"surf: use LC", PT_BOOL, POFF(use_light_cache_tail), false, {}},
+    {"volume: use LC", PT_BOOL, POFF(volume_use_light_cache), false, {}},
+    {"LC grid type", PT_OPTION, POFF(lc_grid_type), true, {"exponential", "quadratic"}},
+    {"LC buf size", PT_UINT, POFF(lc_buffer_size), true, {}},
+    {"LC grid tan(alpha/2)", PT_FLOAT, POFF(lc_grid_tan_alpha_half), false, {}},
+    {"LC grid steps per unit", PT_FLOAT, POFF(lc_grid_steps_per_unit_size), false, {}},
+    {"LC grid min width", PT_FLOAT, POFF(lc_grid_min_width), false, {}},
+    {"LC grid power", PT_FLOAT, POFF(lc_grid_power), false, {}},
+    {"debug output", PT_OPTION, POFF(debug_output_selector), false, {"light cache", "mc weight", "mc mean direction", "mc grid", "irradiance", "moments", "mc cos", "mc N", "mc motion vectors"}},
+    // GBuffer node (default_config.json:527-535)
+    {"hide sun", PT_BOOL, POFF(hide_sun), false, {}},
+    {"enable albedo mipmap", PT_BOOL, POFF(enable_albedo_mipmap), false, {}},
+    {"enable emission mipmap", PT_BOOL, POFF(enable_emission_mipmap), false, {}},
+    // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
+    {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
+    {"quirk: 16-bit N*N", PT_BOOL, POFF(quirk_n16_wrap), false, {}},
+};
+const int k_nprops = (int)(sizeof(k_props) / sizeof(k_props[0]));
+
+const PropDesc* find_prop(const char* key) {
+    for (int i = 0; i < k_nprops; i++) if (!strcmp(k_props[i].key, key)) return &k_props[i];
+    return nullptr;
+}
+double prop_get(const MqProps& p, const PropDesc& d) {
+    const char* b = (const char*)&p + d.off;
+    switch (d.type) {
+    case PT_BOOL: return *(const bool*)b ? 1.0 : 0.0;
+    case PT_INT: case PT_OPTION: return (double)*(const int*)b;
+    case PT_UINT: return (double)*(const uint32_t*)b;
+    case PT_FLOAT: return (double)*(const float*)b;
+    }
+    return 0.0;
+}
+bool prop_set(MqProps& p, const PropDesc& d, double v) { // returns true if the value changed
+    char* b = (char*)&p + d.off;
+    switch (d.type) {
+    case PT_BOOL: { bool n = v != 0.0; bool ch = *(bool*)b != n; *(bool*)b = n; return ch; }
+    case PT_INT: case PT_OPTION: { int n = (int)std::llround(v); bool ch = *(int*)b != n; *(int*)b = n; return ch; }
+    case PT_UINT: { uint32_t n = (uint32_t)std::llround(v); bool ch = *(uint32_t*)b != n; *(uint32_t*)b = n; return ch; }
+    case PT_FLOAT: { float n = (float)v; bool ch = *(float*)b != n; *(float*)b = n; return ch; }
+    }
+    return false;
+}
+
+// ---- a small JSON reader: enough for merian-quake graph files ---------------------------------
+struct JParser {
+    const char* s; size_t n, i = 0; bool ok = true;
+    JParser(const char* t) : s(t), n(strlen(t)) {}
+    void ws() { while (i < n && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++; }
+    bool eat(char c) { ws(); if (i < n && s[i] == c) { i++; return true; } return false; }
+    std::string str() {
+        std::string r; ws();
+        if (i >= n || s[i] != '"') { ok = false; return r; }
+        i++;
+        while (i < n && s[i] != '"') { if (s[i] == '\\' && i + 1 < n) { i++; } r.push_back(s[i++]); }
+        if (i < n) i++; else ok = false;
+        return r;
+    }
+    void skip() { // skip any value
+        ws();
+        if (i >= n) { ok = false; return; }
+        if (s[i] == '"') { str(); return; }
+        if (s[i] == '{' || s[i] == '[') {
+            char open = s[i], close = open == '{' ? '}' : ']'; i++;
+            ws();
+            if (i < n && s[i] == close) { i++; return; }
+            for (;;) {
+                if (open == '{') { str(); if (!eat(':')) { ok = false; return; } }
+                skip(); if (!ok) return;
+                if (eat(',')) continue;
+                if (eat(close)) return;
+                ok = false; return;
+            }
+        }
+        while (i < n && s[i] != ',' && s[i] != '}' && s[i] != ']' && s[i] != ' ' && s[i] != '\n' && s[i] != '\r' && s[i] != '\t') i++;
+    }
+    // positions the cursor at the value of `key` inside the object starting at the cursor
+    bool find_key(const std::string& key) {
+        if (!eat('{')) return false;
+        ws();
+        if (i < n && s[i] == '}') return false;
+        for (;;) {
+            std::string k = str();
+            if (!ok || !eat(':')) return false;
+            if (k == key) return true;
+            skip(); if (!ok) return false;
+            if (eat(',')) continue;
+            return false;
+        }
+    }
+};
+
+void props_to_params(mq_ctx* c) {
+    const MqProps& q = c->props; MqParams& P = c->params;
+    memset(&P, 0, sizeof P);
+    P.reference_mode = (q.reference_mode || q.surf_bsdf_p == 1.0f) ? 1 : 0; // render_mcpg.cpp:139-140
+    P.adaptive_grid_type = q.mc_adaptive_grid_type; P.spp = q.spp; P.max_path_length = q.max_path_length;
+    P.use_light_cache_tail = q.use_light_cache_tail; P.fov_tan_alpha_half = c->constants.fov_tan_alpha_half;
+    for (int k = 0; k < 3; k++) { P.sun_w[k] = c->constants.sun_direction[k]; P.sun_color[k] = c->constants.sun_color[k]; }
+    P.volume_spp = q.volume_spp; P.volume_use_light_cache = q.volume_use_light_cache;
+    P.draine_g = (float)std::exp(-2.20679 / ((double)q.volume_particle_size_um + 3.91029) - 0.428934); // render_mcpg.cpp:134
+    P.draine_a = (float)std::exp(3.62489 - 8.29288 / ((double)q.volume_particle_size_um + 5.52825));   // render_mcpg.cpp:135
+    P.mc_samples = q.mc_samples; P.mc_samples_adaptive_prob = q.mc_samples_adaptive_prob;
+    P.distance_mc_samples = q.distance_mc_samples; P.mc_fast_recovery = q.mc_fast_recovery; P.lc_grid_type = q.lc_grid_type;
+    P.lc_buffer_size = c->lc_total ? c->lc_total : q.lc_buffer_size;
+    P.lc_grid_steps_per_unit_size = q.lc_grid_steps_per_unit_size; P.lc_grid_tan_alpha_half = q.lc_grid_tan_alpha_half;
+    P.lc_grid_min_width = q.lc_grid_min_width; P.lc_grid_power = q.lc_grid_power;
+    P.mc_adaptive_buffer_size = q.mc_adaptive_buffer_size; P.mc_adaptive_grid_tan_alpha_half = q.mc_adaptive_grid_tan_alpha_half;
+    P.mc_adaptive_grid_min_width = q.mc_adaptive_grid_min_width; P.mc_adaptive_grid_power = q.mc_adaptive_grid_power;
+    P.mc_adaptive_grid_steps_per_unit_size = q.mc_adaptive_grid_steps_per_unit_size;
+    P.mc_static_buffer_size = q.mc_static_buffer_size; P.mc_static_grid_width = q.mc_static_grid_width;
+    P.distance_mc_grid_width = q.distance_mc_grid_width; P.volume_max_t = c->constants.volume_max_t;
+    P.surf_bsdf_p = q.surf_bsdf_p; P.volume_phase_p = q.volume_phase_p; P.dir_guide_prior = q.dir_guide_prior; P.dist_guide_p = q.dist_guide_p;
+    P.distance_mc_vertex_state_count = q.distance_mc_vertex_state_count;
+    if (q.randomize_seed) { std::random_device dev; std::mt19937 rng(dev()); c->props.seed = (uint32_t)rng(); } // render_mcpg.cpp:127-132
+    P.seed = c->props.seed;
+    P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
+    P.debug_output_selector = q.debug_output_selector;
+    c->params_dirty = false;
+}
+
+void free_frame_state(mq_ctx* c) {
+    for (auto& b : c->d_out) dev_free(b);
+    dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
+    dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
+    c->connected = false;
+}
+void free_scene_dev(mq_ctx* c) {
+    dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_texdesc); dev_free(c->d_texels); dev_free(c->d_lut);
+    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
+}
+
+const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16};
+
+void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
+    memset(d, 0, sizeof *d);
+    d->width = w; d->height = h;
+    size_t px = (size_t)w * h;
+    uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8, nt = tx * ty;
+    uint32_t tpr = (nt + (uint32_t)c->world - 1) / (uint32_t)c->world;
+    for (int i = 0; i < MQ_OUT_COUNT; i++) { d->bytes_per_pixel[i] = k_bpp[i]; d->bytes[i] = px * k_bpp[i]; }
+    d->bytes[MQ_OUT_TILES] = (size_t)tpr * 64 * 16;
+    size_t mc_total = (size_t)c->props.mc_adaptive_buffer_size + c->props.mc_static_buffer_size; // render_mcpg.cpp:59
+    d->state_bytes_markovchain = mc_total * sizeof(MqMCState) + mc_total * 8;
+    d->state_bytes_lightcache = (size_t)c->props.lc_buffer_size * sizeof(MqLCCell);
+    size_t local_px = (size_t)tpr * 64;
+    size_t segs = local_px * (size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1);
+    d->state_bytes_update_queue = segs * sizeof(MqUpdate);
+}
+
+} // namespace
+
+// ================================================================================================
+extern "C" {
+
+int mq_abi_version(void) { return MQ_ABI_VERSION; }
+
+int mq_create(mq_ctx** out, int device) {
+    if (!out) return MQ_EINVAL;
+    *out = nullptr;
+    mq_ctx* c = new (std::nothrow) mq_ctx();
+    if (!c) return MQ_ENOMEM;
+    c->device = -1;
+    c->constants.fov = 90.0f; c->constants.fov_tan_alpha_half = 1.0f; c->constants.volume_max_t = 1000.0f;
+    c->constants.sun_direction[0] = c->constants.sun_direction[1] = c->constants.sun_direction[2] = 0.57735026919f;
+    if (device >= 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || device >= n) { delete c; return MQ_ENODEVICE; }
+        if (hipSetDevice(device) != hipSuccess) { delete c; return MQ_ENODEVICE; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return MQ_ENODEVICE; }
+        c->cu_count = prop.multiProcessorCount;
+        c->device = device;
+        for (auto& e3 : c->ev) if (hipEventCreate(&e3) != hipSuccess) { delete c; return MQ_EHIP; }
+    }
+    *out = c;
+    return MQ_OK;
+}
+
+void mq_destroy(mq_ctx* c) {
+    if (!c) return;
+    if (c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        free_frame_state(c); free_scene_dev(c);
+        for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    }
+    delete c;
+}
+
+const char* mq_last_error(const mq_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// ---- properties --------------------------------------------------------------------------------
+int mq_property_count(void) { return k_nprops; }
+const char* mq_property_name(int i) { return (i >= 0 && i < k_nprops) ? k_props[i].key : nullptr; }
+
+int mq_set_property(mq_ctx* c, const char* key, double value) {
+    if (!c || !key) return MQ_EINVAL;
+    const PropDesc* d = find_prop(key);
+    if (!d) return fail(c, MQ_EUNKNOWN_KEY, std::string("unknown property: ") + key);
+    if (!strcmp(key, "mc samples") && (value < 0 || value > MQ_MAX_MC_SAMPLES)) return fail(c, MQ_EINVAL, "mc samples must be in [0, 8] in this build");
+    if (d->type == PT_OPTION) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
+    bool changed = prop_set(c->props, *d, value);
+    if (changed) c->params_dirty = true;
+    if (changed && d->reconnect) { c->connected = false; return 1; } // NEEDS_RECONNECT, render_mcpg.cpp:567-575
+    return 0;
+}
+int mq_set_property_str(mq_ctx* c, const char* key, const char* value) {
+    if (!c || !key || !value) return MQ_EINVAL;
+    const PropDesc* d = find_prop(key);
+    if (!d) return fail(c, MQ_EUNKNOWN_KEY, std::string("unknown property: ") + key);
+    if (d->type == PT_OPTION) {
+        for (int i = 0; i < 10 && d->options[i]; i++) if (!strcmp(d->options[i], value)) return mq_set_property(c, key, i);
+        return fail(c, MQ_EINVAL, std::string("unknown option '") + value + "' for " + key);
+    }
+    if (d->type == PT_BOOL) { if (!strcmp(value, "true")) return mq_set_property(c, key, 1); if (!strcmp(value, "false")) return mq_set_property(c, key, 0); }
+    char* end = nullptr; double v = strtod(value, &end);
+    if (end == value) return fail(c, MQ_EINVAL, std::string("not a number: ") + value);
+    return mq_set_property(c, key, v);
+}
+int mq_get_property(const mq_ctx* c, const char* key, double* value) {
+    if (!c || !key || !value) return MQ_EINVAL;
+    const PropDesc* d = find_prop(key);
+    if (!d) return MQ_EUNKNOWN_KEY;
+    *value = prop_get(c->props, *d);
+    return MQ_OK;
+}
+void mq_properties_header_defaults(mq_ctx* c) { if (!c) return; c->props = MqProps(); c->params_dirty = true; c->connected = false; }
+void mq_properties_json_defaults(mq_ctx* c) { // res/default_config.json:527-535,599-638
+    if (!c) return;
+    MqProps p;
+    p.surf_bsdf_p = 0.1f; p.lc_buffer_size = 4000037; p.lc_grid_min_width = 0.01f; p.lc_grid_power = 2.0f; p.lc_grid_steps_per_unit_size = 6.0f;
+    p.lc_grid_tan_alpha_half = 0.005f; p.lc_grid_type = 1; p.dir_guide_prior = 0.3f; p.volume_phase_p = 0.1f;
+    p.mc_adaptive_buffer_size = 32777259; p.mc_adaptive_grid_min_width = 0.01f; p.mc_adaptive_grid_power = 1.7320508f; p.mc_samples_adaptive_prob = 0.7f;
+    p.mc_adaptive_grid_steps_per_unit_size = 1.0f; p.mc_adaptive_grid_tan_alpha_half = 0.002f; p.mc_adaptive_grid_type = 0;
+    p.dist_guide_p = 0.9f; p.distance_mc_grid_width = 25; p.distance_mc_samples = 3; p.distance_mc_vertex_state_count = 10;
+    p.max_path_length = 3; p.mc_fast_recovery = true; p.mc_samples = 5; p.mc_static_grid_width = 25.3f; p.volume_particle_size_um = 7.0f;
+    p.randomize_seed = true; p.reference_mode = false; p.spp = 2; p.mc_static_buffer_size = 800009; p.use_light_cache_tail = false;
+    p.volume_forward_project = true; p.volume_spp = 2; p.volume_use_light_cache = true;
+    c->props = p; c->params_dirty = true; c->connected = false;
+}
+
+int mq_load_properties_json(mq_ctx* c, const char* json_text, const char* node_name) {
+    if (!c || !json_text || !node_name) return MQ_EINVAL;
+    // graph files keep nodes under {"graph": {"nodes": {...}}} or {"nodes": {...}}; accept both, or a bare properties object
+    const char* paths[3][4] = {{"graph", "nodes", node_name, "properties"}, {"nodes", node_name, "properties", nullptr}, {node_name, "properties", nullptr, nullptr}};
+    for (auto& path : paths) {
+        JParser jp(json_text);
+        bool found = true;
+        for (int k = 0; k < 4 && path[k]; k++) if (!jp.find_key(path[k])) { found = false; break; }
+        if (!found) continue;
+        if (!jp.eat('{')) return fail(c, MQ_EIO, "properties is not an object");
+        int applied = 0, reconnect = 0;
+        jp.ws();
+        if (jp.i < jp.n && jp.s[jp.i] == '}') return 0;
+        for (;;) {
+            std::string k = jp.str();
+            if (!jp.ok || !jp.eat(':')) return fail(c, MQ_EIO, "malformed properties object");
+            jp.ws();
+            size_t v0 = jp.i; bool is_str = jp.i < jp.n && jp.s[jp.i] == '"';
+            std::string sval;
+            if (is_str) sval = jp.str(); else { jp.skip(); sval.assign(jp.s + v0, jp.i - v0); }
+            if (!jp.ok) return fail(c, MQ_EIO, "malformed property value");
+            if (find_prop(k.c_str())) { int r = mq_set_property_str(c, k.c_str(), sval.c_str()); if (r < 0) return r; reconnect |= r; applied++; }
+            if (jp.eat(',')) continue;
+            break;
+        }
+        (void)applied;
+        return reconnect;
+    }
+    return fail(c, MQ_EIO, std::string("node not found in json: ") + node_name);
+}
+
+// ---- scene -------------------------------------------------------------------------------------
+int mq_scene_set_geometry(mq_ctx* c, int slot, const float* vtx, const float* prev_vtx, uint32_t n_vtx, const uint32_t* idx, const mq_ext* ext, uint32_t n_tri, uint32_t flags) {
+    if (!c || slot < 0 || slot >= MQ_MAX_GEOMETRIES) return fail(c, MQ_EINVAL, "geometry slot out of range");
+    MqHostGeo& g = c->geo[slot];
+    g = MqHostGeo();
+    c->committed = false;
+    if (n_tri == 0) return MQ_OK;
+    if (!vtx || !idx || !ext) return fail(c, MQ_EINVAL, "null geometry arrays");
+    if (n_tri >= (1u << 28)) return fail(c, MQ_EINVAL, "too many triangles in one slot");
+    for (uint32_t i = 0; i < 3 * n_tri; i++) if (idx[i] >= n_vtx) return fail(c, MQ_EINVAL, "index out of range");
+    g.vtx.assign(vtx, vtx + 3 * (size_t)n_vtx);
+    g.prev_vtx.assign(prev_vtx ? prev_vtx : vtx, (prev_vtx ? prev_vtx : vtx) + 3 * (size_t)n_vtx);
+    g.idx.assign(idx, idx + 3 * (size_t)n_tri);
+    g.ext.assign(ext, ext + n_tri);
+    g.flags = flags;
+    return MQ_OK;
+}
+int mq_scene_set_texture(mq_ctx* c, uint32_t texnum, uint32_t w, uint32_t h, const uint8_t* rgba8, uint32_t flags) {
+    if (!c || texnum >= MQ_MAX_GLTEXTURES) return fail(c, MQ_EINVAL, "texnum out of range");
+    if (w > 65535 || h > 65535) return fail(c, MQ_EINVAL, "texture too large");
+    MqHostTex& t = c->tex[texnum];
+    t = MqHostTex();
+    c->committed = false;
+    if (!rgba8 || !w || !h) return MQ_OK;
+    t.w = w; t.h = h; t.flags = flags; t.px.assign(rgba8, rgba8 + (size_t)w * h * 4);
+    return MQ_OK;
+}
+int mq_scene_get_geometry(const mq_ctx* c, int slot, const float** vtx, const float** prev_vtx, uint32_t* n_vtx, const uint32_t** idx, const mq_ext** ext, uint32_t* n_tri, uint32_t* flags) {
+    if (!c || slot < 0 || slot >= MQ_MAX_GEOMETRIES) return MQ_EINVAL;
+    const MqHostGeo& g = c->geo[slot];
+    if (vtx) *vtx = g.vtx.data(); if (prev_vtx) *prev_vtx = g.prev_vtx.data(); if (n_vtx) *n_vtx = (uint32_t)(g.vtx.size() / 3);
+    if (idx) *idx = g.idx.data(); if (ext) *ext = g.ext.data(); if (n_tri) *n_tri = g.n_tri(); if (flags) *flags = g.flags;
+    return MQ_OK;
+}
+int mq_scene_get_texture(const mq_ctx* c, uint32_t texnum, uint32_t* w, uint32_t* h, const uint8_t** rgba8, uint32_t* flags) {
+    if (!c || texnum >= MQ_MAX_GLTEXTURES) return MQ_EINVAL;
+    const MqHostTex& t = c->tex[texnum];
+    if (w) *w = t.w; if (h) *h = t.h; if (rgba8) *rgba8 = t.px.empty() ? nullptr : t.px.data(); if (flags) *flags = t.flags;
+    return MQ_OK;
+}
+int mq_scene_stats(const mq_ctx* c, uint64_t* n_tris, uint64_t* n_nodes, uint64_t* bvh_bytes, float* sah_cost) {
+    if (!c) return MQ_EINVAL;
+    if (n_tris) *n_tris = c->tris.size(); if (n_nodes) *n_nodes = c->nodes.size();
+    if (bvh_bytes) *bvh_bytes = c->nodes.size() * sizeof(MqNode) + c->tris.size() * sizeof(MqTri);
+    if (sah_cost) *sah_cost = c->sah_cost;
+    return MQ_OK;
+}
+
+int mq_scene_commit(mq_ctx* c) {
+    if (!c) return MQ_EINVAL;
+    std::vector<MqTri> flat;
+    size_t total = 0;
+    for (auto& g : c->geo) total += g.n_tri();
+    flat.reserve(total);
+    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) {
+        MqHostGeo& g = c->geo[s];
+        g.dynamic = g.prev_vtx.size() == g.vtx.size() && !g.vtx.empty() && memcmp(g.prev_vtx.data(), g.vtx.data(), g.vtx.size() * 4) != 0;
+        for (uint32_t i = 0; i < g.n_tri(); i++) {
+            MqTri t; memset(&t, 0, sizeof t);
+            memcpy(t.v0, &g.vtx[3 * (size_t)g.idx[3 * i]], 12); memcpy(t.v1, &g.vtx[3 * (size_t)g.idx[3 * i + 1]], 12); memcpy(t.v2, &g.vtx[3 * (size_t)g.idx[3 * i + 2]], 12);
+            t.key = ((uint32_t)s << 28) | i;
+            t.flags = ((g.flags & MQ_GEO_OPAQUE) ? 0u : MQ_TRI_ANYHIT) | (g.dynamic ? MQ_TRI_DYNAMIC : 0u);
+            flat.push_back(t);
+        }
+    }
+    std::string err;
+    if (!mq_build_cwbvh(flat, c->nodes, c->tris, &c->sah_cost, err)) return fail(c, MQ_EINVAL, "bvh build: " + err);
+    c->committed = true;
+    if (c->device < 0) return MQ_OK; // host-only context: BVH available for inspection, nothing to upload
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    free_scene_dev(c);
+    int r;
+    if ((r = dev_upload(c, c->d_nodes, c->nodes.data(), c->nodes.size() * sizeof(MqNode)))) return r;
+    if ((r = dev_upload(c, c->d_tris, c->tris.data(), c->tris.size() * sizeof(MqTri)))) return r;
+    memset(&c->scene, 0, sizeof c->scene);
+    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) {
+        MqHostGeo& g = c->geo[s];
+        if (!g.n_tri()) continue;
+        if ((r = dev_upload(c, c->d_ext[s], g.ext.data(), g.ext.size() * sizeof(mq_ext)))) return r;
+        c->scene.geo[s].ext = (const mq_ext*)c->d_ext[s].p;
+        if (g.dynamic) {
+            if ((r = dev_upload(c, c->d_idx[s], g.idx.data(), g.idx.size() * 4))) return r;
+            if ((r = dev_upload(c, c->d_prev[s], g.prev_vtx.data(), g.prev_vtx.size() * 4))) return r;
+            c->scene.geo[s].idx = (const uint32_t*)c->d_idx[s].p; c->scene.geo[s].prev_vtx = (const float*)c->d_prev[s].p;
+        }
+    }
+    std::vector<MqTexDesc> desc(MQ_MAX_GLTEXTURES);
+    std::vector<uint32_t> pool;
+    for (uint32_t t = 0; t < MQ_MAX_GLTEXTURES; t++) {
+        const MqHostTex& tx = c->tex[t];
+        if (tx.px.empty()) { desc[t].offset = MQ_NIL; desc[t].w = desc[t].h = 0; desc[t].flags = 0; continue; }
+        desc[t].offset = (uint32_t)pool.size(); desc[t].w = (uint16_t)tx.w; desc[t].h = (uint16_t)tx.h; desc[t].flags = tx.flags;
+        size_t n = (size_t)tx.w * tx.h;
+        size_t at = pool.size(); pool.resize(at + n);
+        memcpy(&pool[at], tx.px.data(), n * 4);
+    }
+    if ((r = dev_upload(c, c->d_texdesc, desc.data(), desc.size() * sizeof(MqTexDesc)))) return r;
+    if ((r = dev_upload(c, c->d_texels, pool.data(), pool.size() * 4))) return r;
+    float lut[256];
+    for (int i = 0; i < 256; i++) { double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4)); }
+    if ((r = dev_upload(c, c->d_lut, lut, sizeof lut))) return r;
+    c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p;
+    c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const uint32_t*)c->d_texels.p; c->scene.srgb_lut = (const float*)c->d_lut.p;
+    c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
+    return MQ_OK;
+}
+
+int mq_set_constants(mq_ctx* c, const mq_constants* k) {
+    if (!c || !k) return MQ_EINVAL;
+    c->constants = *k; c->params_dirty = true; // constant_data_update -> pipeline refresh, render_mcpg.cpp:125
+    return MQ_OK;
+}
+
+int mq_get_constants(const mq_ctx* c, mq_constants* out) { if (!c || !out) return MQ_EINVAL; *out = c->constants; return MQ_OK; }
+
+// ---- describe / connect / process ---------------------------------------------------------------
+int mq_describe(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* out) {
+    if (!c || !out || !w || !h) return MQ_EINVAL;
+    fill_desc(c, w, h, out);
+    return MQ_OK;
+}
+
+int mq_set_partition(mq_ctx* c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, MQ_EINVAL, "bad partition");
+    if (rank != c->rank || world != c->world) c->connected = false;
+    c->rank = rank; c->world = world;
+    return MQ_OK;
+}
+int mq_tiles_per_rank(const mq_ctx* c, uint32_t* tiles, size_t* bytes) {
+    if (!c || !c->W) return MQ_ESTATE;
+    if (tiles) *tiles = c->tiles_per_rank; if (bytes) *bytes = (size_t)c->tiles_per_rank * 64 * 16;
+    return MQ_OK;
+}
+
+int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
+    if (!c || !w || !h) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    if (c->props.mc_samples > MQ_MAX_MC_SAMPLES) return fail(c, MQ_EINVAL, "mc samples exceeds kernel limit");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    free_frame_state(c);
+    c->W = w; c->H = h; c->tiles_x = (w + 7) / 8; c->tiles_y = (h + 7) / 8;
+    uint32_t nt = c->tiles_x * c->tiles_y;
+    c->tiles_per_rank = (nt + (uint32_t)c->world - 1) / (uint32_t)c->world;
+    c->n_local_tiles = (nt > (uint32_t)c->rank) ? (nt - (uint32_t)c->rank + (uint32_t)c->world - 1) / (uint32_t)c->world : 0;
+    mq_io_desc d; fill_desc(c, w, h, &d);
+    int r;
+    for (int i = 0; i < MQ_OUT_COUNT; i++) { if ((r = dev_alloc(c, c->d_out[i], d.bytes[i]))) return r; HIPCHK(c, hipMemset(c->d_out[i].p, 0, c->d_out[i].bytes)); }
+    c->mc_total = c->props.mc_adaptive_buffer_size + c->props.mc_static_buffer_size;
+    c->lc_total = c->props.lc_buffer_size;
+    if ((r = dev_alloc(c, c->d_mc, (size_t)c->mc_total * sizeof(MqMCState)))) return r;
+    if ((r = dev_alloc(c, c->d_lc, (size_t)c->lc_total * sizeof(MqLCCell)))) return r;
+    if ((r = dev_alloc(c, c->d_upd_count, (size_t)c->mc_total * 4))) return r;
+    if ((r = dev_alloc(c, c->d_upd_head, (size_t)c->mc_total * 4))) return r;
+    size_t segs = (size_t)c->tiles_per_rank * 64 * (size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1);
+    c->queue_cap = (uint32_t)std::min<size_t>(segs, 0x7fffffffu);
+    if ((r = dev_alloc(c, c->d_queue, (size_t)c->queue_cap * sizeof(MqUpdate)))) return r;
+    if ((r = dev_alloc(c, c->d_ctrl, 64))) return r;
+    if ((r = dev_alloc(c, c->d_counters, sizeof(MqCountersDev)))) return r;
+    HIPCHK(c, hipMemset(c->d_counters.p, 0, sizeof(MqCountersDev)));
+    int per_cu = std::max(1, mq_render_blocks_per_cu(true, true));
+    c->grid_blocks = std::max(1, c->cu_count) * std::min(per_cu, 8);
+    if ((r = dev_alloc(c, c->d_spill, (size_t)c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
+    c->iteration = 0; c->connected = true; c->params_dirty = true;
+    return MQ_OK;
+}
+
+int mq_reset_state(mq_ctx* c) { if (!c) return MQ_EINVAL; c->iteration = 0; return MQ_OK; }
+
+static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
+    memset(&F, 0, sizeof F);
+    F.u = *u; F.W = c->W; F.H = c->H; F.tiles_x = c->tiles_x; F.tiles_y = c->tiles_y;
+    F.n_local_tiles = c->n_local_tiles; F.rank = (uint32_t)c->rank; F.world = (uint32_t)c->world;
+    F.irradiance = (float*)c->d_out[MQ_OUT_IRRADIANCE].p; F.tiles_out = (float*)c->d_out[MQ_OUT_TILES].p;
+    F.gb_albedo = (uint16_t*)c->d_out[MQ_OUT_GB_ALBEDO].p; F.gb_irr = (uint16_t*)c->d_out[MQ_OUT_GB_IRRADIANCE].p;
+    F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
+    F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
+    F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.counters = (MqCountersDev*)c->d_counters.p;
+    F.stack_spill = (unsigned long long*)c->d_spill.p;
+}
+
+int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
+    if (!c || !u) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    if (!c->connected) return fail(c, MQ_ESTATE, "mq_process before mq_connect (or a property change needs a reconnect)");
+    if (!c->committed) return fail(c, MQ_ESTATE, "mq_process before mq_scene_commit");
+    hipStream_t s = (hipStream_t)stream;
+    c->last_stream = s;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->params_dirty) props_to_params(c);
+    MqFrame F; fill_frame(c, u, F);
+    if (c->iteration == 0) { // render_mcpg.cpp:221-226
+        HIPCHK(c, hipMemsetAsync(c->d_mc.p, 0, c->d_mc.bytes, s));
+        HIPCHK(c, hipMemsetAsync(c->d_lc.p, 0, c->d_lc.bytes, s));
+        HIPCHK(c, hipMemsetAsync(c->d_upd_count.p, 0, c->d_upd_count.bytes, s));
+        HIPCHK(c, hipMemsetAsync(c->d_upd_head.p, 0, c->d_upd_head.bytes, s));
+    }
+    c->iteration++;
+    if (!render) { // render_mcpg.cpp:243-250
+        int e = mq_launch_clear(F, s);
+        if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
+        c->ev_valid = false;
+        return MQ_OK;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, 64, s));
+    if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(MqCountersDev), s));
+    const bool guided = !c->params.reference_mode;
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    int e = mq_launch_render(c->scene, c->params, F, guided, c->count_enabled, c->grid_blocks, s);
+    if (e) return fail(c, MQ_EHIP, std::string("render launch: ") + hipGetErrorString((hipError_t)e));
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (guided) { // render_mcpg.cpp:261-277
+        e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, s);
+        if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    c->ev_valid = true;
+    return MQ_OK;
+}
+
+int mq_sync(mq_ctx* c) {
+    if (!c) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    return MQ_OK;
+}
+int mq_map_output(mq_ctx* c, int which, void** dev_ptr, size_t* bytes) {
+    if (!c || which < 0 || which >= MQ_OUT_COUNT) return MQ_EINVAL;
+    if (!c->d_out[which].p) return fail(c, MQ_ESTATE, "not connected");
+    if (dev_ptr) *dev_ptr = c->d_out[which].p; if (bytes) *bytes = c->d_out[which].bytes;
+    return MQ_OK;
+}
+int mq_read_output(mq_ctx* c, int which, void* dst, size_t bytes) {
+    if (!c || !dst || which < 0 || which >= MQ_OUT_COUNT) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->d_out[which].p) return fail(c, MQ_ESTATE, "not connected");
+    if (bytes > c->d_out[which].bytes) return fail(c, MQ_EINVAL, "read larger than the output");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    HIPCHK(c, hipMemcpy(dst, c->d_out[which].p, bytes, hipMemcpyDeviceToHost));
+    return MQ_OK;
+}
+int mq_last_frame_ms(mq_ctx* c, float* total_ms, float* render_ms, float* update_ms) {
+    if (!c) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->ev_valid) return fail(c, MQ_ESTATE, "no timed frame yet");
+    HIPCHK(c, hipEventSynchronize(c->ev[2]));
+    float a = 0, b = 0;
+    HIPCHK(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    if (render_ms) *render_ms = a; if (update_ms) *update_ms = b; if (total_ms) *total_ms = a + b;
+    return MQ_OK;
+}
+int mq_enable_counters(mq_ctx* c, int on) { if (!c) return MQ_EINVAL; c->count_enabled = on != 0; return MQ_OK; }
+int mq_get_counters(mq_ctx* c, mq_counters* out) {
+    if (!c || !out) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->d_counters.p) return fail(c, MQ_ESTATE, "not connected");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    MqCountersDev d;
+    HIPCHK(c, hipMemcpy(&d, c->d_counters.p, sizeof d, hipMemcpyDeviceToHost));
+    out->rays = d.rays; out->nodes = d.nodes; out->tris = d.tris; out->segments = d.segments; out->guided_segments = d.guided_segments;
+    out->lc_touches = d.lc_touches; out->mc_updates_accepted = d.mc_updates_accepted; out->mc_updates_dropped = d.mc_updates_dropped;
+    out->mc_state_reads = d.mc_state_reads; out->pixels = d.pixels;
+    return MQ_OK;
+}
+
+int mq_untile(mq_ctx* c, const void* gathered_dev, void* stream) {
+    if (!c || !gathered_dev) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
+    HIPCHK(c, hipSetDevice(c->device));
+    int e = mq_launch_untile(gathered_dev, c->d_out[MQ_OUT_IRRADIANCE].p, c->W, c->H, c->tiles_x, c->tiles_x * c->tiles_y, (uint32_t)c->world, c->tiles_per_rank, (hipStream_t)stream);
+    if (e) return fail(c, MQ_EHIP, std::string("untile launch: ") + hipGetErrorString((hipError_t)e));
+    return MQ_OK;
+}
+
+// ---- queries -----------------------------------------------------------------------------------
+int mq_trace_rays(mq_ctx* c, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv) {
+    if (!c || !org || !dir || !prim || !t) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    if (!c->committed) return fail(c, MQ_ESTATE, "scene not committed");
+    if (n == 0) return MQ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf d_o, d_d, d_p, d_t, d_uv, d_sp;
+    int grid = std::min<int>((int)((n + 255) / 256), std::max(1, c->cu_count) * 8);
+    int r = 0;
+    if (!r) r = dev_upload(c, d_o, org, (size_t)n * 12);
+    if (!r) r = dev_upload(c, d_d, dir, (size_t)n * 12);
+    if (!r) r = dev_alloc(c, d_p, (size_t)n * 4);
+    if (!r) r = dev_alloc(c, d_t, (size_t)n * 4);
+    if (!r) r = dev_alloc(c, d_uv, (size_t)n * 8);
+    if (!r) r = dev_alloc(c, d_sp, (size_t)grid * 256 * mq_spill_entries() * 8);
+    if (!r) { int e = mq_launch_trace(c->scene, (const float*)d_o.p, (const float*)d_d.p, n, (uint32_t*)d_p.p, (float*)d_t.p, (float*)d_uv.p, (unsigned long long*)d_sp.p, grid, nullptr); if (e) r = fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e)); }
+    if (!r && hipDeviceSynchronize() != hipSuccess) r = fail(c, MQ_EHIP, "trace kernel failed");
+    if (!r && hipMemcpy(prim, d_p.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
+    if (!r && hipMemcpy(t, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
+    if (!r && uv && hipMemcpy(uv, d_uv.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
+    dev_free(d_o); dev_free(d_d); dev_free(d_p); dev_free(d_t); dev_free(d_uv); dev_free(d_sp);
+    return r;
+}
+
+static const int k_arity[14][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}};
+int mq_math_eval(mq_ctx* c, int op, const float* in, float* out, uint32_t n) {
+    if (!c || !in || !out || op < 0 || op >= 14) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    if (n == 0) return MQ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->params_dirty) props_to_params(c);
+    int ni = k_arity[op][0], no = k_arity[op][1];
+    DevBuf d_in, d_out; int r = 0;
+    if (!r) r = dev_upload(c, d_in, in, (size_t)n * ni * 4);
+    if (!r) r = dev_alloc(c, d_out, (size_t)n * no * 4);
+    if (!r) { int e = mq_launch_math(c->scene, c->params, op, ni, no, (const float*)d_in.p, (float*)d_out.p, n, nullptr); if (e) r = fail(c, MQ_EHIP, std::string("math launch: ") + hipGetErrorString((hipError_t)e)); }
+    if (!r && hipDeviceSynchronize() != hipSuccess) r = fail(c, MQ_EHIP, "math kernel failed");
+    if (!r && hipMemcpy(out, d_out.p, (size_t)n * no * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
+    dev_free(d_in); dev_free(d_out);
+    return r;
+}
+
+// ---- scene sources -----------------------------------------------------------------------------
+int mq_synth_scene(mq_ctx* c, const char* name, uint32_t seed) {
+    if (!c || !name) return MQ_EINVAL;
+    std::string err;
+    if (!mq_synth_generate(c, name, seed, err)) return fail(c, MQ_EINVAL, err);
+    c->params_dirty = true;
+    return MQ_OK;
+}
+
+static void catmull(const std::vector<float>& p, float t, float out[3], float tan[3]) {
+    size_t n = p.size() / 3;
+    float ft = std::floor(t);
+    long i1 = (long)ft; float f = t - ft;
+    auto at = [&](long i, int k) { long m = (long)n; long j = ((i % m) + m) % m; return p[3 * (size_t)j + k]; };
+    for (int k = 0; k < 3; k++) {
+        float p0 = at(i1 - 1, k), p1 = at(i1, k), p2 = at(i1 + 1, k), p3 = at(i1 + 2, k);
+        float a = -0.5f * p0 + 1.5f * p1 - 1.5f * p2 + 0.5f * p3, b = p0 - 2.5f * p1 + 2.0f * p2 - 0.5f * p3, cc = -0.5f * p0 + 0.5f * p2;
+        out[k] = ((a * f + b) * f + cc) * f + p1;
+        tan[k] = (3.0f * a * f + 2.0f * b) * f + cc;
+    }
+}
+
+int mq_synth_camera(const mq_ctx* c, uint32_t frame, mq_uniform* u) {
+    if (!c || !u) return MQ_EINVAL;
+    if (!c->synth.valid) return MQ_ESTATE;
+    memset(u, 0, sizeof *u);
+    const MqSynthInfo& s = c->synth;
+    auto cam = [&](uint32_t f, float* x, float* w, float* up) {
+        float pos[3], tan[3];
+        catmull(s.path, 0.37f + s.speed * (float)f, pos, tan);
+        float l = std::sqrt(tan[0] * tan[0] + tan[1] * tan[1]);
+        if (l < 1e-6f) { tan[0] = 1; tan[1] = 0; l = 1; }
+        // look along the path, slightly upward, so ceilings / sky and floors are both in view
+        float fw[3] = {tan[0] / l, tan[1] / l, 0.12f};
+        float fl = std::sqrt(fw[0] * fw[0] + fw[1] * fw[1] + fw[2] * fw[2]);
+        for (int k = 0; k < 3; k++) fw[k] /= fl;
+        // AngleVectors-style basis: right = fw x world_up, up = right x fw
+        float r[3] = {fw[1], -fw[0], 0.0f};
+        float rl = std::sqrt(r[0] * r[0] + r[1] * r[1]);
+        r[0] /= rl; r[1] /= rl;
+        float uu[3] = {r[1] * fw[2] - r[2] * fw[1], r[2] * fw[0] - r[0] * fw[2], r[0] * fw[1] - r[1] * fw[0]};
+        for (int k = 0; k < 3; k++) { x[k] = pos[k]; w[k] = fw[k]; up[k] = uu[k]; }
+    };
+    cam(frame, u->cam_x, u->cam_w, u->cam_u);
+    cam(frame ? frame - 1 : 0, u->prev_cam_x, u->prev_cam_w, u->prev_cam_u);
+    u->cam_x[3] = s.mu_t; u->cam_w[3] = 1.0f / 60.0f; u->cam_u[3] = 0.0f; // TIME_DIFF, quake_node.cpp:787-790
+    u->prev_cam_x[3] = s.mu_s[0]; u->prev_cam_w[3] = s.mu_s[1]; u->prev_cam_u[3] = s.mu_s[2];
+    u->sky_rt_bk = s.sky_rt_bk; u->sky_lf_ft = 0xffffu; u->sky_up_dn = 0xffffffffu; // classic sky marker, raytrace.glsl:35
+    u->cl_time = (float)frame / 60.0f; u->frame = frame; u->player = 0; u->rt_config = 0;
+    return MQ_OK;
+}
+
+int mq_load_bsp(mq_ctx* c, const char* bsp_path, const char* palette_path) {
+    if (!c || !bsp_path) return MQ_EINVAL;
+    std::string err;
+    if (!mq_bsp_load(c, bsp_path, palette_path, err)) return fail(c, MQ_EIO, err);
+    c->params_dirty = true;
+    return MQ_OK;
+}
+
+} // extern "C"

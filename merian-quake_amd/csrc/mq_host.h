@@ -1,0 +1,89 @@
+// mq_host.h -- host-side internals of libmqhip (scene container, property table, launch glue).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mq_types.h"
+
+struct MqHostGeo {
+    std::vector<float> vtx, prev_vtx;
+    std::vector<uint32_t> idx;
+    std::vector<mq_ext> ext;
+    uint32_t flags = 0;
+    bool dynamic = false; // prev_vtx differs from vtx
+    uint32_t n_tri() const { return (uint32_t)(idx.size() / 3); }
+};
+struct MqHostTex {
+    uint32_t w = 0, h = 0, flags = 0;
+    std::vector<uint8_t> px;
+};
+
+struct MqSynthInfo {
+    bool valid = false;
+    std::vector<float> path; // camera control points xyz
+    float eye_height = 0.0f;
+    float speed = 0.0f;      // control points per frame
+    float mu_t = 0.0f;
+    float mu_s[3] = {0, 0, 0};
+    uint32_t sky_rt_bk = 18u | (19u << 16); // classic sky layers: back | front << 16
+};
+
+// The reference's property set (src/render_mcpg/render_mcpg.hpp:108-166 + gbuffer.hpp:75-77)
+struct MqProps {
+    bool randomize_seed = true;
+    uint32_t seed = 0;
+    bool reference_mode = false;
+    float dir_guide_prior = 0.2f;
+    int mc_samples = 5;
+    float mc_samples_adaptive_prob = 0.7f;
+    int mc_adaptive_grid_type = 0;
+    uint32_t mc_adaptive_buffer_size = 32777259;
+    float mc_adaptive_grid_tan_alpha_half = 0.003f;
+    float mc_adaptive_grid_steps_per_unit_size = 6.0f;
+    float mc_adaptive_grid_min_width = 0.01f;
+    float mc_adaptive_grid_power = 4.0f;
+    uint32_t mc_static_buffer_size = 800009;
+    float mc_static_grid_width = 25.3f;
+    bool mc_fast_recovery = true;
+    int spp = 1;
+    int max_path_length = 3;
+    float surf_bsdf_p = 0.15f;
+    int volume_spp = 0;
+    int distance_mc_samples = 3;
+    int distance_mc_grid_width = 25;
+    uint32_t distance_mc_vertex_state_count = 10;
+    float volume_particle_size_um = 25.0f;
+    float dist_guide_p = 0.0f;
+    float volume_phase_p = 0.3f;
+    bool volume_forward_project = true;
+    bool use_light_cache_tail = false;
+    bool volume_use_light_cache = false;
+    int lc_grid_type = 0;
+    uint32_t lc_buffer_size = 4000000;
+    float lc_grid_tan_alpha_half = 0.002f;
+    float lc_grid_steps_per_unit_size = 6.0f;
+    float lc_grid_min_width = 0.01f;
+    float lc_grid_power = 2.0f;
+    int debug_output_selector = 0;
+    // gbuffer node
+    bool hide_sun = true;
+    bool enable_albedo_mipmap = true;
+    bool enable_emission_mipmap = true;
+    // named quirk switches
+    bool quirk_lc_max_wo_p = true;
+    bool quirk_n16_wrap = false;
+};
+
+bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err);
+
+struct mq_ctx;
+bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string& err);
+bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, std::string& err);
+
+// host-side access used by the generators / loaders
+MqHostGeo& mq_ctx_geo(mq_ctx* ctx, int slot);
+MqHostTex& mq_ctx_tex(mq_ctx* ctx, uint32_t texnum);
+mq_constants& mq_ctx_constants(mq_ctx* ctx);
+MqSynthInfo& mq_ctx_synth(mq_ctx* ctx);
+void mq_ctx_clear_scene(mq_ctx* ctx);

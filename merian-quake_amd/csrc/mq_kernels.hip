@@ -1,0 +1,935 @@
+// mq_kernels.hip -- hand-written gfx950 kernels of the MCPG path tracer.
+//
+//   mq_render_kernel     persistent-wavefront megakernel: primary ray (g-buffer node,
+//                        res/shader/gbuffer/gbuffer.comp:75-131) + surface estimator
+//                        (res/shader/render_mcpg/mcpg.comp:39-210) over a software CWBVH.
+//   mq_apply_kernel      Markov-chain update application (compute_updates.comp:56-124) over a
+//                        compact update queue instead of the reference's 17 GB slot array.
+//   mq_clear_kernel      clear.comp:15-23 + the CLEAR variant of gbuffer.comp:83-90.
+//   mq_untile_kernel     multi-GPU: gathered tile-major radiance -> full image.
+//   mq_trace_kernel      closest-hit queries (raytrace.glsl:82-119 semantics).
+//   mq_math_kernel       device-side known-answer evaluation of the shading primitives.
+//
+// Scheduling: one path per lane.  A wave pulls pixels from a global counter with one aggregated
+// atomic per refill (ballot + mbcnt), so lanes whose path ended are re-armed immediately and the
+// single traversal call site always sees the maximum number of live rays (primary and bounce rays
+// share it).  Traversal stacks live in LDS ([entry][lane] layout, conflict free) with a global
+// spill area behind them.  No MFMA: the path is divergent traversal, not a contraction.
+#include "mq_device.h"
+
+#define MQ_BLOCK 256
+#define MQ_WAVES (MQ_BLOCK / 64)
+#define MQ_STACK_LDS 12
+#define MQ_SPILL_ENTRIES 52
+
+struct RayHit { uint32_t tri; float t, u, v; };
+
+struct Hit { // res/shader/hit.glsl.h:6-17
+    f3 pos, prev_pos, wi, normal;
+    uint32_t enc_geonormal;
+    f3 albedo;
+    float roughness;
+};
+
+struct Ctr { uint32_t rays, nodes, tris, segments, guided, lc, upd_ok, upd_drop, mc_reads, pixels, lc_ok, lc_cancel; };
+
+// ------------------------------------------------------------------------------------------------
+// textures: RGBA8 texel pool, REPEAT wrap, nearest or bilinear, sRGB decode through a LUT
+// ------------------------------------------------------------------------------------------------
+struct f4 { float r, g, b, a; };
+
+MQ_DEV int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+
+MQ_DEV f4 texel(const MqSceneDev& sc, const MqTexDesc& t, int x, int y) {
+    uint32_t p = sc.texels[t.offset + (uint32_t)wrapi(y, (int)t.h) * t.w + (uint32_t)wrapi(x, (int)t.w)];
+    f4 r;
+    if (t.flags & MQ_TEX_SRGB) { r.r = sc.srgb_lut[p & 0xff]; r.g = sc.srgb_lut[(p >> 8) & 0xff]; r.b = sc.srgb_lut[(p >> 16) & 0xff]; }
+    else { r.r = (float)(p & 0xff) * (1.0f / 255.0f); r.g = (float)((p >> 8) & 0xff) * (1.0f / 255.0f); r.b = (float)((p >> 16) & 0xff) * (1.0f / 255.0f); }
+    r.a = (float)(p >> 24) * (1.0f / 255.0f);
+    return r;
+}
+MQ_DEV f4 tex_sample(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
+    if (texnum > MQ_MAX_GLTEXTURES - 1) texnum = MQ_MAX_GLTEXTURES - 1;
+    MqTexDesc tx = sc.tex[texnum];
+    if (tx.offset == MQ_NIL) { f4 g; g.r = g.g = g.b = 0.5f; g.a = 1.0f; return g; }
+    float fw = (float)tx.w, fh = (float)tx.h;
+    if (!(tx.flags & MQ_TEX_LINEAR)) return texel(sc, tx, (int)floorf(s * fw), (int)floorf(t * fh));
+    float x = s * fw - 0.5f, y = t * fh - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    int ix = (int)x0, iy = (int)y0;
+    f4 a = texel(sc, tx, ix, iy), b = texel(sc, tx, ix + 1, iy), d = texel(sc, tx, ix, iy + 1), e = texel(sc, tx, ix + 1, iy + 1);
+    f4 r;
+    r.r = mmix(mmix(a.r, b.r, fx), mmix(d.r, e.r, fx), fy);
+    r.g = mmix(mmix(a.g, b.g, fx), mmix(d.g, e.g, fx), fy);
+    r.b = mmix(mmix(a.b, b.b, fx), mmix(d.b, e.b, fx), fy);
+    r.a = mmix(mmix(a.a, b.a, fx), mmix(d.a, e.a, fx), fy);
+    return r;
+}
+MQ_DEV float tex_gather_alpha_r(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
+    if (texnum > MQ_MAX_GLTEXTURES - 1) texnum = MQ_MAX_GLTEXTURES - 1;
+    MqTexDesc tx = sc.tex[texnum];
+    if (tx.offset == MQ_NIL) return 1.0f;
+    int ix = (int)floorf(s * (float)tx.w - 0.5f), iy = (int)floorf(t * (float)tx.h - 0.5f);
+    return texel(sc, tx, ix, iy + 1).a;
+}
+
+MQ_DEV mq_ext load_ext(const MqSceneDev& sc, uint32_t key) {
+    // 28-byte records are 4-byte aligned: 7 dword loads
+    const uint32_t* p = (const uint32_t*)(sc.geo[key >> 28].ext + (key & 0x0fffffffu));
+    union { mq_ext e; uint32_t w[7]; } u;
+#pragma unroll
+    for (int i = 0; i < 7; i++) u.w[i] = p[i];
+    return u.e;
+}
+
+// any-hit confirmation, raytrace.glsl:100-118
+MQ_DEV bool anyhit_confirm(const MqSceneDev& sc, uint32_t key, float u, float v) {
+    mq_ext e = load_ext(sc, key);
+    uint32_t flags = e.texnum_fb_flags >> 12, alpha = e.texnum_alpha >> 12;
+    if (flags > 0 && flags < 7) return true;
+    if (alpha != 0) return rh((float)(alpha - 1) / 14.0f) >= MQ_ALPHA_THRESHOLD;
+    float b0 = 1.0f - u - v;
+    float s = h2f(e.st[0]) * b0 + h2f(e.st[2]) * u + h2f(e.st[4]) * v;
+    float t = h2f(e.st[1]) * b0 + h2f(e.st[3]) * u + h2f(e.st[5]) * v;
+    return tex_gather_alpha_r(sc, e.texnum_alpha & 0xfffu, s, t) >= MQ_ALPHA_THRESHOLD;
+}
+
+// ------------------------------------------------------------------------------------------------
+// traversal of the 8-wide compressed BVH
+// ------------------------------------------------------------------------------------------------
+
+// Moeller-Trumbore, front faces only (geometric normal = cross(v2-v0, v1-v0), raytrace.glsl:221-223;
+// back faces culled, raytrace.glsl:73,85).  Exact op order matters: results are compared bit for bit.
+MQ_DEV bool tri_isect(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float& t, float& u, float& v) {
+    f3 e1 = v1 - v0, e2 = v2 - v0;
+    f3 pv = cross(d, e2);
+    float det = dot(e1, pv);
+    if (!(det < 0.0f)) return false;
+    float inv = 1.0f / det;
+    f3 tv = o - v0;
+    float uu = dot(tv, pv) * inv;
+    if (!(uu >= -MQ_BARY_EPS) || !(uu <= 1.0f + MQ_BARY_EPS)) return false;
+    f3 qv = cross(tv, e1);
+    float vv = dot(d, qv) * inv;
+    if (!(vv >= -MQ_BARY_EPS) || !(uu + vv <= 1.0f + MQ_BARY_EPS)) return false;
+    float tt = dot(e2, qv) * inv;
+    if (!(tt > 0.0f)) return false;
+    t = tt; u = uu; v = vv;
+    return true;
+}
+
+MQ_DEV float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
+
+// One group of four children: bytes of nq/fq hold near/far quantised planes per axis.
+MQ_DEV uint32_t box4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t meta,
+                     float adx, float ady, float adz, float ox, float oy, float oz, float tlim, uint32_t octinv) {
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float tnx = __builtin_fmaf(ub(nx, j), adx, ox), tfx = __builtin_fmaf(ub(fx, j), adx, ox);
+        float tny = __builtin_fmaf(ub(ny, j), ady, oy), tfy = __builtin_fmaf(ub(fy, j), ady, oy);
+        float tnz = __builtin_fmaf(ub(nz, j), adz, oz), tfz = __builtin_fmaf(ub(fz, j), adz, oz);
+        float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        float tf = fminf(fminf(tfx, tfy), fminf(tfz, tlim));
+        uint32_t m = (meta >> (8 * j)) & 0xffu;
+        if (m != 0 && tn <= tf) {
+            uint32_t inner = (m & 0x18u) == 0x18u ? 1u : 0u;
+            uint32_t bit = (m & 31u) ^ (inner ? octinv : 0u);
+            mask |= (m >> 5) << bit;
+        }
+    }
+    return mask;
+}
+
+template <bool COUNT>
+MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, float tmax, RayHit& hit, uint2* stk /* &lds[0][lane] */,
+                     unsigned long long* spill, Ctr& ctr) {
+    hit.tri = MQ_NIL; hit.t = __uint_as_float(0x7f800000u); hit.u = 0.0f; hit.v = 0.0f;
+    uint32_t best_key = MQ_NIL;
+    if (COUNT) ctr.rays++;
+    if (sc.n_nodes == 0) return;
+    float idx = 1.0f / (fabsf(d.x) > 1e-20f ? d.x : (d.x < 0.0f ? -1e-20f : 1e-20f));
+    float idy = 1.0f / (fabsf(d.y) > 1e-20f ? d.y : (d.y < 0.0f ? -1e-20f : 1e-20f));
+    float idz = 1.0f / (fabsf(d.z) > 1e-20f ? d.z : (d.z < 0.0f ? -1e-20f : 1e-20f));
+    const bool sx = d.x < 0.0f, sy = d.y < 0.0f, sz = d.z < 0.0f;
+    const uint32_t octinv = (sx ? 0u : 1u) | (sy ? 0u : 2u) | (sz ? 0u : 4u);
+    uint2 G = make_uint2(0u, 0x80000000u);
+    int sp = 0;
+    for (;;) {
+        // pop the nearest remaining child of the current node group
+        uint32_t bit = 31u - (uint32_t)__clz((int)G.y);
+        G.y &= ~(1u << bit);
+        if (G.y > 0x00ffffffu) {
+            if (sp < MQ_STACK_LDS) stk[sp * 64] = G;
+            else spill[sp - MQ_STACK_LDS] = ((unsigned long long)G.y << 32) | G.x;
+            sp++;
+        }
+        uint32_t slot = (bit - 24u) ^ octinv;
+        uint32_t rel = (uint32_t)__popc(G.y & 0xffu & ((1u << slot) - 1u));
+        const uint4* np = (const uint4*)(sc.nodes + (G.x + rel));
+        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        if (COUNT) ctr.nodes++;
+        float tlim = fminf(hit.t, tmax) * 1.000001f + 1e-6f;
+        float adx = __uint_as_float((n0.w & 0xffu) << 23) * idx;
+        float ady = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * idy;
+        float adz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * idz;
+        float ox = (__uint_as_float(n0.x) - o.x) * idx;
+        float oy = (__uint_as_float(n0.y) - o.y) * idy;
+        float oz = (__uint_as_float(n0.z) - o.z) * idz;
+        // near / far plane bytes per axis, by ray direction sign
+        uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
+        uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
+        uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
+        uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, octinv) |
+                      box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, octinv);
+        G.x = n1.x;
+        G.y = (hm & 0xff000000u) | (n0.w >> 24);
+        uint32_t tmask = hm & 0x00ffffffu;
+        const uint32_t tbase = n1.y;
+        while (tmask) {
+            uint32_t k = (uint32_t)__ffs((int)tmask) - 1u;
+            tmask &= tmask - 1u;
+            const uint4* tp = (const uint4*)(sc.tris + (tbase + k));
+            uint4 a = tp[0], b = tp[1], c = tp[2];
+            if (COUNT) ctr.tris++;
+            float t, u, v;
+            if (!tri_isect(o, d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
+                           F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
+                           F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), t, u, v))
+                continue;
+            if (!(t < tmax)) continue;
+            if (t < hit.t || (t == hit.t && c.y < best_key)) {
+                if ((c.z & MQ_TRI_ANYHIT) && !anyhit_confirm(sc, c.y, u, v)) continue;
+                hit.t = t; hit.u = u; hit.v = v; hit.tri = tbase + k; best_key = c.y;
+            }
+        }
+        if (G.y <= 0x00ffffffu) {
+            if (sp == 0) break;
+            sp--;
+            if (sp < MQ_STACK_LDS) G = stk[sp * 64];
+            else { unsigned long long e = spill[sp - MQ_STACK_LDS]; G = make_uint2((uint32_t)e, (uint32_t)(e >> 32)); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sky + trace_ray shading (raytrace.glsl:25-65,156-311)
+// ------------------------------------------------------------------------------------------------
+MQ_DEV f3 get_sky(const MqSceneDev& sc, const MqParams& P, const mq_uniform& U, f3 w, f3 sun_color) {
+    f3 sun = F3(P.sun_w[0], P.sun_w[1], P.sun_w[2]);
+    float a = 0.5f * (1.0f + dot(sun, w));
+    float a2 = a * a;
+    float glow = 0.5f * (a2 * a2) + 5.0f * vmf_pdf(w, sun, 3000.0f);
+    f3 emm = rh3(sun_color * rh(glow));
+    if ((U.sky_lf_ft & 0xffffu) == 0xffffu) {
+        float az = fabsf(w.z);
+        float s = 0.5f + w.x / az, t = 0.5f + w.y / az;
+        float tm = U.cl_time * 0.12f;
+        f4 bck = tex_sample(sc, U.sky_rt_bk & 0xffffu, s + 0.5f * tm, t + 0.5f * tm);
+        f4 fnt = tex_sample(sc, U.sky_rt_bk >> 16, s + tm, t + tm);
+        f3 tex = F3(mmix(bck.r, fnt.r, fnt.a), mmix(bck.g, fnt.g, fnt.a), mmix(bck.b, fnt.b, fnt.a));
+        emm = rh3(F3(10.0f * (mq_exp2(3.5f * rh(tex.x)) - 1.0f), 10.0f * (mq_exp2(3.5f * rh(tex.y)) - 1.0f), 10.0f * (mq_exp2(3.5f * rh(tex.z)) - 1.0f)));
+    } else {
+        float ax = fabsf(w.x), ay = fabsf(w.y), az = fabsf(w.z);
+        int side_i;
+        if (ax >= ay && ax >= az) side_i = w.x >= 0.0f ? 0 : 1; else if (ay >= az) side_i = w.y >= 0.0f ? 2 : 3; else side_i = w.z >= 0.0f ? 4 : 5;
+        uint32_t side = 0; float s = 0.0f, t = 0.0f;
+        switch (side_i) {
+        case 0: side = U.sky_rt_bk & 0xffffu; s = 0.5f + 0.5f * -w.y / ax; t = 0.5f + 0.5f * -w.z / ax; break;
+        case 1: side = U.sky_lf_ft & 0xffffu; s = 0.5f + 0.5f * w.y / ax; t = 0.5f + 0.5f * -w.z / ax; break;
+        case 2: side = U.sky_rt_bk >> 16; s = 0.5f + 0.5f * w.x / ay; t = 0.5f + 0.5f * -w.z / ay; break;
+        case 3: side = U.sky_lf_ft >> 16; s = 0.5f + 0.5f * -w.x / ay; t = 0.5f + 0.5f * -w.z / ay; break;
+        case 4: side = U.sky_up_dn & 0xffffu; s = 0.5f + 0.5f * -w.y / az; t = 0.5f + 0.5f * w.x / az; break;
+        default: side = U.sky_up_dn >> 16; s = 0.5f + 0.5f * -w.y / az; t = 0.5f + 0.5f * -w.x / az; break;
+        }
+        if (side < MQ_MAX_GLTEXTURES) { f4 tx = tex_sample(sc, side, s, t); emm = rh3(F3(emm.x + rh(tx.r), emm.y + rh(tx.g), emm.z + rh(tx.b))); }
+    }
+    return emm;
+}
+
+MQ_DEV f3 ld3(const float* p, uint32_t i) { return F3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+// Shades the closest hit `rhit` of the ray (hit.pos, hit.wi).  Mirrors raytrace.glsl:166-311.
+MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform& U, const RayHit& rhit,
+                      f3& throughput, f3& contribution, Hit& hit, f3 sun_color) {
+    float tq = rhit.tri == MQ_NIL ? MQ_T_MAX : rhit.t;
+    float tr = rh(transmittance(tq, U.cam_x[3], P.volume_max_t));
+    throughput = rh3(throughput * tr);
+    hit.roughness = rh(0.6f);
+    uint32_t key = 0, tflags = 0;
+    f3 p0, p1, p2;
+    mq_ext e;
+    uint32_t flags = 0;
+    bool have = rhit.tri != MQ_NIL;
+    if (have) {
+        const uint4* tp = (const uint4*)(sc.tris + rhit.tri);
+        uint4 a = tp[0], b = tp[1], c = tp[2];
+        p0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        p1 = F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+        p2 = F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+        key = c.y; tflags = c.z;
+        e = load_ext(sc, key);
+        flags = e.texnum_fb_flags >> 12;
+    }
+    if (!have || flags == MQ_MAT_FLAGS_SKY) { // :170-194
+        f3 sky = get_sky(sc, P, U, hit.wi, sun_color);
+        f3 add = rh3(throughput * sky);
+        contribution = have ? rh3(contribution + add) : add;
+        hit.albedo = sky;
+        hit.pos = hit.pos + hit.wi * MQ_T_MAX; hit.prev_pos = hit.pos;
+        hit.normal = -hit.wi; hit.enc_geonormal = encode_normal(hit.normal);
+        return;
+    }
+    float b0 = 1.0f - rhit.u - rhit.v, b1 = rhit.u, b2 = rhit.v;
+    float st0s = h2f(e.st[0]), st0t = h2f(e.st[1]), st1s = h2f(e.st[2]), st1t = h2f(e.st[3]), st2s = h2f(e.st[4]), st2t = h2f(e.st[5]);
+    float s = st0s * b0 + st1s * b1 + st2s * b2, t = st0t * b0 + st1t * b1 + st2t * b2;
+    if (flags > 0 && flags < 5) { // :198-204
+        float ws = s + 0.125f * mq_sin(8.0f * t + U.cl_time), wt = t + 0.125f * mq_sin(8.0f * s + U.cl_time);
+        s = ws; t = wt;
+        if (flags == MQ_MAT_FLAGS_WATER) {
+            float as = 0.02f * mq_sin(20.0f * t + 1.7f * U.cl_time), at = 0.02f * mq_sin(20.0f * s + 1.3f * U.cl_time);
+            s += as; t += at;
+            hit.roughness = rh(0.4f);
+        }
+    }
+    hit.pos = (p0 * b0 + p1 * b1) + p2 * b2;
+    f3 du = p2 - p0, dv = p1 - p0;
+    hit.normal = normalize(cross(du, dv));
+    hit.enc_geonormal = encode_normal(hit.normal);
+    if (tflags & MQ_TRI_DYNAMIC) { // :226-228
+        const MqGeoDev& g = sc.geo[key >> 28];
+        uint32_t prim = key & 0x0fffffffu;
+        uint32_t i0 = g.idx[3 * prim], i1 = g.idx[3 * prim + 1], i2 = g.idx[3 * prim + 2];
+        hit.prev_pos = (ld3(g.prev_vtx, i0) * b0 + ld3(g.prev_vtx, i1) * b1) + ld3(g.prev_vtx, i2) * b2;
+    } else hit.prev_pos = hit.pos;
+    f4 at = tex_sample(sc, e.texnum_alpha & 0xfffu, s, t);
+    f3 albedo_tex = rh3(F3(mq_pow(rh(at.r), 1.0f / 1.2f), mq_pow(rh(at.g), 1.0f / 1.2f), mq_pow(rh(at.b), 1.0f / 1.2f)));
+    if (e.n1_brush == 0xffffffffu) { // :249-274
+        uint32_t tn_norm = e.n0_gloss_norm >> 16, tn_gloss = e.n0_gloss_norm & 0xffffu;
+        if (tn_norm > 0 && tn_norm < MQ_MAX_GLTEXTURES) {
+            f4 nt = tex_sample(sc, tn_norm, s, t);
+            f3 tn = F3((nt.r - 0.5f) * 2.0f, (nt.g - 0.5f) * 2.0f, (nt.b - 0.5f) * 2.0f);
+            float d0x = rh(st2s - st0s), d0y = rh(st2t - st0t), d1x = rh(st1s - st0s), d1y = rh(st1t - st0t);
+            float det = rh(rh(d0x * d1y) - rh(d1x * d0y));
+            if (fabsf(det) > 1e-8f) {
+                f3 du2 = normalize((du * d1y - dv * d0y) * (1.0f / det));
+                dv = -normalize((du * (-d1x) + dv * d0x) * (1.0f / det));
+                du = du2;
+            }
+            f3 gn = hit.normal;
+            hit.normal = normalize((du * tn.x + dv * tn.y) + gn * tn.z);
+            f3 r = hit.wi - hit.normal * (2.0f * dot(hit.wi, hit.normal));
+            if (dot(r, gn) < 0.0f) hit.normal = normalize(-hit.wi + normalize(r - gn * dot(gn, r)));
+        }
+        if (tn_gloss > 0 && tn_gloss < MQ_MAX_GLTEXTURES) hit.roughness = rh(tex_sample(sc, tn_gloss, s, t).r);
+    } else if (flags == MQ_MAT_FLAGS_SOLID) { // :275-278
+        uint32_t a = e.n0_gloss_norm, b = e.n1_brush;
+        hit.albedo = rh3(F3(rh((float)(a & 0xff)) / 255.0f, rh((float)((a >> 8) & 0xff)) / 255.0f, rh((float)((a >> 16) & 0xff)) / 255.0f));
+        f3 em = ldr_to_hdr(rh3(F3(rh((float)(b & 0xff)) / 255.0f, rh((float)((b >> 8) & 0xff)) / 255.0f, rh((float)((b >> 16) & 0xff)) / 255.0f)));
+        contribution = rh3(contribution + rh3(throughput * em));
+        return;
+    }
+    if (flags == MQ_MAT_FLAGS_WATERFALL) { // :288-310
+        hit.albedo = albedo_tex;
+        contribution = rh3(contribution + rh3(throughput * hit.albedo));
+    } else if (flags == MQ_MAT_FLAGS_SPRITE || flags == MQ_MAT_FLAGS_TELE) {
+        hit.albedo = ldr_to_hdr(albedo_tex);
+        contribution = rh3(contribution + rh3(throughput * hit.albedo));
+    } else {
+        uint32_t fb = e.texnum_fb_flags & 0xfffu;
+        hit.albedo = albedo_tex;
+        if (fb > 0 && fb < MQ_MAX_GLTEXTURES) {
+            f4 ft = tex_sample(sc, fb, s, t);
+            f3 em = ldr_to_hdr(rh3(F3(ft.r, ft.g, ft.b)));
+            if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {
+                contribution = rh3(contribution + rh3(throughput * em));
+                hit.albedo = em;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hash-grid addressing (mc.glsl:62-88,117-121; light_cache.glsl:13-29)
+// ------------------------------------------------------------------------------------------------
+MQ_DEV uint32_t grid_level(int type, float steps, float tan_half, float minw, float power, f3 cam, f3 pos) {
+    float w = 2.0f * tan_half * length(cam - pos);
+    float lv;
+    if (type == 0) lv = steps * mq_log(mmax(w, minw) / minw) / mq_log(power);
+    else lv = steps * mq_pow(mmax(w - minw, 0.0f), 1.0f / power);
+    return (uint32_t)floorf(lv + 0.5f);
+}
+MQ_DEV float grid_width(int type, float steps, float minw, float power, uint32_t level) {
+    if (type == 0) return minw * mq_pow(power, (float)level / steps);
+    return mq_pow((float)level / steps, power) + minw;
+}
+MQ_DEV f3 cam_pos(const mq_uniform& U) { return F3(U.cam_x[0], U.cam_x[1], U.cam_x[2]); }
+
+MQ_DEV void mc_adaptive_buffer_index(const MqParams& P, const mq_uniform& U, uint32_t& rng, f3 pos, f3 normal, uint32_t& index, uint32_t& hash16) {
+    uint32_t level = grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, cam_pos(U), pos);
+    float xi = xorshift(rng);
+    level += (uint32_t)(-mq_log2(1.0f - xi));
+    float width = grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, level);
+    i3 g = grid_idx_interpolate(pos, width, xorshift(rng));
+    index = hash_grid_normal_level(g, normal, level, P.mc_adaptive_buffer_size);
+    hash16 = hash2_grid_level(g, level) & 0xffffu;
+}
+MQ_DEV void mc_static_buffer_index(const MqParams& P, uint32_t& rng, f3 pos, uint32_t& index, uint32_t& hash16) {
+    i3 g = grid_idx_interpolate(pos, P.mc_static_grid_width, xorshift(rng));
+    index = hash_grid(g, P.mc_static_buffer_size) + P.mc_adaptive_buffer_size;
+    hash16 = hash2_grid(g) & 0xffffu;
+}
+
+// Markov-chain state in registers
+struct MCS { f3 w_tgt; float sum_w, w_cos, T; uint32_t id, N, hash; uint16_t mv[3]; };
+
+MQ_DEV MCS mc_load(const MqMCState* mc, uint32_t i) {
+    const uint4* p = (const uint4*)(mc + i);
+    uint4 a = p[0], b = p[1];
+    uint2 c = *(const uint2*)(p + 2);
+    MCS s;
+    s.w_tgt = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)); s.sum_w = __uint_as_float(a.w);
+    s.w_cos = __uint_as_float(b.x); s.T = __uint_as_float(b.y); s.id = b.z; s.N = b.w & 0xffffu; s.hash = b.w >> 16;
+    s.mv[0] = (uint16_t)(c.x & 0xffffu); s.mv[1] = (uint16_t)(c.x >> 16); s.mv[2] = (uint16_t)(c.y & 0xffffu);
+    return s;
+}
+MQ_DEV void mc_store(MqMCState* mc, uint32_t i, const MCS& s) {
+    uint4* p = (uint4*)(mc + i);
+    p[0] = make_uint4(__float_as_uint(s.w_tgt.x), __float_as_uint(s.w_tgt.y), __float_as_uint(s.w_tgt.z), __float_as_uint(s.sum_w));
+    p[1] = make_uint4(__float_as_uint(s.w_cos), __float_as_uint(s.T), s.id, (s.N & 0xffffu) | (s.hash << 16));
+    *(uint2*)(p + 2) = make_uint2((uint32_t)s.mv[0] | ((uint32_t)s.mv[1] << 16), (uint32_t)s.mv[2]);
+}
+MQ_DEV f3 mc_state_pos(const MCS& s) { return s.sum_w > 0.0f ? s.w_tgt * (1.0f / s.sum_w) : s.w_tgt; }
+MQ_DEV f3 mc_state_dir(const MCS& s, f3 pos) { return normalize(mc_state_pos(s) - pos); }
+MQ_DEV float mc_state_mean_cos(const MqParams& P, const MCS& s, f3 pos) { // mc.glsl:24-26
+    f3 d = pos - mc_state_pos(s);
+    float prior = mmax(0.0001f, P.dir_guide_prior / dot(d, d));
+    uint32_t nn = s.N * s.N;
+    if (P.quirk_n16_wrap) nn &= 0xffffu;
+    float n2 = (float)nn;
+    return (n2 * mclamp(s.w_cos / s.sum_w, 0.0f, 0.9999999f)) / (n2 + prior);
+}
+MQ_DEV float mc_state_kappa(const MqParams& P, const MCS& s, f3 pos) { // mc.glsl:43-46
+    float r = mc_state_mean_cos(P, s, pos);
+    return (3.0f * r - r * r * r) / (1.0f - r * r);
+}
+MQ_DEV MCS mc_state_new(uint32_t& rng) { // mc.glsl:17
+    MCS s;
+    s.id = (uint32_t)(xorshift(rng) * 4294967296.0f);
+    s.w_tgt = F3(0.0f, 0.0f, 0.0f); s.sum_w = 0.0f; s.w_cos = 0.0f; s.T = 0.0f; s.N = 0; s.hash = 0; s.mv[0] = s.mv[1] = s.mv[2] = 0;
+    return s;
+}
+MQ_DEV void mc_finalize_load(const mq_uniform& U, MCS& s, uint32_t hash16, bool is_static, f3 pos, f3 normal) { // mc.glsl:90-96,130-135
+    bool bad = s.sum_w < 0.0f || hash16 != s.hash;
+    if (!bad && is_static) bad = !(dot(normal, mc_state_dir(s, pos)) > 0.0f);
+    if (bad) s.sum_w = 0.0f;
+    float k = s.sum_w * (U.cl_time - s.T);
+    s.w_tgt = s.w_tgt + F3(h2f(s.mv[0]), h2f(s.mv[1]), h2f(s.mv[2])) * k;
+}
+
+// ---- light cache (light_cache.glsl:31-84) ------------------------------------------------------
+MQ_DEV void lc_address(const MqParams& P, uint32_t& rng, uint32_t level, f3 pos, f3 normal, uint32_t& idx, uint32_t& chk) {
+    float width = grid_width(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_min_width, P.lc_grid_power, level);
+    i3 g = grid_idx_interpolate(pos, width, xorshift(rng));
+    idx = hash_grid_normal_level(g, normal, level, P.lc_buffer_size);
+    chk = hash2_grid_level(g, level);
+}
+MQ_DEV void light_cache_get_level(const MqParams& P, const MqLCCell* lc, uint32_t& rng, f3& irr, uint32_t& N, uint32_t level, f3 pos, f3 normal) {
+    uint32_t idx, chk;
+    lc_address(P, rng, level, pos, normal, idx, chk);
+    uint4 c = *(const uint4*)(lc + idx);
+    uint16_t i0 = (uint16_t)(c.z & 0xffffu), i1 = (uint16_t)(c.z >> 16), i2 = (uint16_t)(c.w & 0xffffu);
+    if (c.x == chk && !h_bad(i0) && !h_bad(i1) && !h_bad(i2)) { irr = F3(h2f(i0), h2f(i1), h2f(i2)); N = c.w >> 16; }
+    else { irr = F3(0.0f, 0.0f, 0.0f); N = 0; }
+}
+MQ_DEV uint32_t lc_level(const MqParams& P, const mq_uniform& U, f3 pos) {
+    return grid_level(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_tan_alpha_half, P.lc_grid_min_width, P.lc_grid_power, cam_pos(U), pos);
+}
+MQ_DEV f3 light_cache_get(const MqParams& P, const mq_uniform& U, const MqLCCell* lc, uint32_t& rng, f3 pos, f3 normal) {
+    f3 irr; uint32_t N;
+    light_cache_get_level(P, lc, rng, irr, N, lc_level(P, U, pos), pos, normal);
+    return irr;
+}
+MQ_DEV void light_cache_update(const MqParams& P, const mq_uniform& U, MqLCCell* lc, uint32_t& rng, f3 pos, f3 normal, f3 irr, Ctr& ctr) {
+    uint32_t level = lc_level(P, U, pos), idx, chk;
+    lc_address(P, rng, level, pos, normal, idx, chk);
+    MqLCCell* cell = lc + idx;
+    uint32_t old = atomicExch(&cell->lock, U.frame);
+    if (old == U.frame) { ctr.lc_cancel++; return; }
+    const volatile uint32_t* vc = (const volatile uint32_t*)cell;
+    uint4 c = make_uint4(vc[0], vc[1], vc[2], vc[3]);
+    uint16_t i0 = (uint16_t)(c.z & 0xffffu), i1 = (uint16_t)(c.z >> 16), i2 = (uint16_t)(c.w & 0xffffu);
+    f3 cur; uint32_t N;
+    if (c.x != chk || h_bad(i0) || h_bad(i1) || h_bad(i2)) {
+        f3 ci; uint32_t cn;
+        light_cache_get_level(P, lc, rng, ci, cn, level + 1, pos, normal);
+        cur = rh3(ci); N = cn;
+    } else { cur = F3(h2f(i0), h2f(i1), h2f(i2)); N = c.w >> 16; }
+    N = N + 1 < MQ_LC_MAX_N ? N + 1 : MQ_LC_MAX_N;
+    float a = mmax(1.0f / (float)N, MQ_LC_MIN_ALPHA);
+    uint32_t o0 = f2h(mmix(cur.x, irr.x, a)), o1 = f2h(mmix(cur.y, irr.y, a)), o2 = f2h(mmix(cur.z, irr.z, a));
+    // hash + irradiance + N in one 16-byte store; the lock word is released by the same store
+    *(uint4*)cell = make_uint4(chk, 0u, o0 | (o1 << 16), o2 | (N << 16));
+    ctr.lc_ok++;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the render megakernel
+// ------------------------------------------------------------------------------------------------
+MQ_DEV void store_chit(uint32_t* dst, const Hit& h) { // hit.glsl.h:34-43, 40-byte record
+    uint32_t m0 = f2h(h.pos.x - h.prev_pos.x), m1 = f2h(h.pos.y - h.prev_pos.y), m2 = f2h(h.pos.z - h.prev_pos.z);
+    uint2* d2 = (uint2*)dst; // 40-byte records are 8-byte aligned
+    d2[0] = make_uint2(__float_as_uint(h.pos.x), __float_as_uint(h.pos.y));
+    d2[1] = make_uint2(__float_as_uint(h.pos.z), m0 | (m1 << 16));
+    d2[2] = make_uint2(m2, encode_normal(h.wi));
+    d2[3] = make_uint2(encode_normal(h.normal), h.enc_geonormal);
+    d2[4] = make_uint2((uint32_t)f2h(h.albedo.x) | ((uint32_t)f2h(h.albedo.y) << 16), (uint32_t)f2h(h.albedo.z) | ((uint32_t)f2h(h.roughness) << 16));
+}
+MQ_DEV void load_chit(const uint32_t* src, Hit& h) { // hit.glsl.h:45-53
+    const uint2* s2 = (const uint2*)src;
+    uint2 a = s2[0], b = s2[1], c = s2[2], d = s2[3], e = s2[4];
+    h.pos = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x));
+    h.prev_pos = F3(h.pos.x - h2f((uint16_t)(b.y & 0xffffu)), h.pos.y - h2f((uint16_t)(b.y >> 16)), h.pos.z - h2f((uint16_t)(c.x & 0xffffu)));
+    h.wi = decode_normal(c.y); h.normal = decode_normal(d.x); h.enc_geonormal = d.y;
+    h.albedo = F3(h2f((uint16_t)(e.x & 0xffffu)), h2f((uint16_t)(e.x >> 16)), h2f((uint16_t)(e.y & 0xffffu)));
+    h.roughness = h2f((uint16_t)(e.y >> 16));
+}
+
+MQ_DEV void flush_counters(MqCountersDev* g, const Ctr& c) {
+    // wave-level reduction, then one atomic per counter per wave
+    const uint32_t v[12] = {c.rays, c.nodes, c.tris, c.segments, c.guided, c.lc, c.upd_ok, c.upd_drop, c.mc_reads, c.pixels, c.lc_ok, c.lc_cancel};
+    unsigned long long* dst = (unsigned long long*)g;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        uint32_t x = v[i];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(dst + i, (unsigned long long)x);
+    }
+}
+
+template <bool GUIDED, bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK) void mq_render_kernel(MqSceneDev sc, MqParams P, MqFrame F) {
+    __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* stk = &s_stack[wave][0][lane];
+    unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * MQ_BLOCK + threadIdx.x) * MQ_SPILL_ENTRIES;
+    const uint32_t total = F.n_local_tiles * 64u;
+    const mq_uniform& U = F.u;
+    const float Wf = (float)F.W, Hf = (float)F.H;
+    const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
+    const f3 gb_sun = P.gbuffer_hide_sun ? F3(0.0f, 0.0f, 0.0f) : sun_color;
+    const int K = P.mc_samples < MQ_MAX_MC_SAMPLES ? P.mc_samples : MQ_MAX_MC_SAMPLES;
+
+    Ctr ctr = {};
+    // path state
+    bool active = false, exhausted = false;
+    uint32_t px = 0, py = 0, lidx = 0, rng = 0;
+    int seg = 0, smp = 0;
+    Hit cur = {};
+    f3 thr = F3(1, 1, 1), fval = F3(0, 0, 0), irr = F3(0, 0, 0);
+    float pp = 1.0f, m2 = 0.0f;
+    f3 ro = F3(0, 0, 0), rd = F3(0, 0, 1);
+    // carried over the trace of a bounce ray
+    float wo_p = 0.0f, bsdf = 0.0f, wodotn = 0.0f, score_sum = 0.0f, mc_sum_w = 0.0f;
+    uint32_t mc_index = MQ_NIL, mc_id = 0;
+    bool lm_dir_ok = false;
+
+    for (;;) {
+        // ---- (re)arm idle lanes with fresh pixels: one aggregated atomic per wave -------------
+        if (!active && !exhausted) {
+            unsigned long long idle = __ballot(1);
+            int leader = __ffsll((long long)idle) - 1;
+            uint32_t n = (uint32_t)__popcll(idle), base = 0;
+            if (lane == leader) base = atomicAdd(&F.ctrl[0], n);
+            base = __shfl(base, leader, 64);
+            uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (my < total) {
+                uint32_t ltile = my >> 6, within = my & 63u;
+                uint32_t gtile = ltile * F.world + F.rank;
+                uint32_t tx = gtile % F.tiles_x, ty = gtile / F.tiles_x;
+                px = tx * 8u + (within & 7u); py = ty * 8u + (within >> 3);
+                lidx = my;
+                active = true; seg = 0; smp = 0;
+                irr = F3(0, 0, 0); m2 = 0.0f;
+                rng = pcg4d16(px, py, U.frame, P.seed); // mcpg.comp:40
+                ro = cam_pos(U);
+                rd = camera_ray_dir((float)px, (float)py, Wf, Hf, F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]), P.fov_tan_alpha_half);
+                if (COUNT) ctr.pixels++;
+            } else exhausted = true;
+        }
+        if (__ballot(active) == 0ull) break;
+
+        // ---- the single traversal call site ----------------------------------------------------
+        RayHit rhit;
+        rhit.tri = MQ_NIL; rhit.t = 0.0f; rhit.u = rhit.v = 0.0f;
+        const bool in_image = px < F.W && py < F.H;
+        if (active && in_image) traverse<COUNT>(sc, ro, rd, MQ_T_MAX, rhit, stk, spill, ctr);
+
+        if (active) {
+            bool need_dir = false, sample_done = false;
+            const size_t pidx = (size_t)py * F.W + px;
+            if (!in_image) { // padding lanes of edge tiles
+                active = false;
+            } else if (seg == 0) {
+                // ---- g-buffer node: gbuffer.comp:75-131 ---------------------------------------
+                Hit h; h.pos = ro; h.wi = rd; h.prev_pos = ro; h.normal = F3(0, 0, 1); h.enc_geonormal = 0; h.albedo = F3(0, 0, 0); h.roughness = 0.0f;
+                f3 incident = F3(0, 0, 0), cthr = F3(1, 1, 1);
+                shade_hit(sc, P, U, rhit, cthr, incident, h, gb_sun);
+                *(uint2*)(F.gb_irr + 4 * pidx) = make_uint2((uint32_t)f2h(incident.x) | ((uint32_t)f2h(incident.y) << 16), (uint32_t)f2h(incident.z) | (0x3c00u << 16));
+                float keep = (incident.x >= 1e-5f || incident.y >= 1e-5f || incident.z >= 1e-5f) ? 0.0f : 1.0f;
+                h.albedo = rh3(rh3(h.albedo * keep) * cthr);
+                *(uint2*)(F.gb_albedo + 4 * pidx) = make_uint2((uint32_t)f2h(h.albedo.x) | ((uint32_t)f2h(h.albedo.y) << 16), (uint32_t)f2h(h.albedo.z) | (0x3c00u << 16));
+                {
+                    f3 old_dir = h.prev_pos - F3(U.prev_cam_x[0], U.prev_cam_x[1], U.prev_cam_x[2]);
+                    float opx, opy;
+                    camera_pixel(old_dir, Wf, Hf, F3(U.prev_cam_u[0], U.prev_cam_u[1], U.prev_cam_u[2]), F3(U.prev_cam_w[0], U.prev_cam_w[1], U.prev_cam_w[2]), P.fov_tan_alpha_half, opx, opy);
+                    *(uint32_t*)(F.gb_mv + 2 * pidx) = (uint32_t)f2h(opx - (float)px) | ((uint32_t)f2h(opy - (float)py) << 16);
+                }
+                store_chit(F.hits + 10 * pidx, h);
+                {
+                    f3 up = F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), fw = F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]);
+                    f3 r_x = camera_ray_dir((float)px + 1.0f, (float)py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
+                    f3 r_y = camera_ray_dir((float)px, (float)py + 1.0f, Wf, Hf, up, fw, P.fov_tan_alpha_half);
+                    f3 gn = decode_normal(h.enc_geonormal);
+                    f3 cp = cam_pos(U);
+                    float lz = length(cp - h.pos);
+                    float num = dot(gn, h.pos - cp);
+                    uint32_t g0 = f2h(num / dot(gn, r_x - h.wi) - lz), g1 = f2h(num / dot(gn, r_y - h.wi) - lz);
+                    float vz = length(F3(U.prev_cam_x[0], U.prev_cam_x[1], U.prev_cam_x[2]) - h.prev_pos) - lz;
+                    *(uint4*)(F.gbuffer + 4 * pidx) = make_uint4(encode_normal(h.normal), __float_as_uint(lz), g0 | (g1 << 16), __float_as_uint(vz));
+                }
+                // ---- mcpg.comp:44: skip pixels whose first hit carries no albedo -------------
+                if ((h.albedo.x >= 1e-7f || h.albedo.y >= 1e-7f || h.albedo.z >= 1e-7f) && P.spp > 0 && P.max_path_length > 1) {
+                    // the surface pass starts from the COMPRESSED first hit (mcpg.comp:46-47)
+                    Hit tmp = h; // compress -> decompress through registers, same values as the stored record
+                    __attribute__((aligned(8))) uint32_t rec[10];
+                    store_chit(rec, tmp);
+                    load_chit(rec, cur);
+                    thr = F3(1, 1, 1); fval = F3(0, 0, 0); pp = 1.0f; seg = 1; smp = 0;
+                    need_dir = true;
+                } else {
+                    seg = 1; smp = P.spp; // nothing to trace: falls through to the pixel store
+                    sample_done = false;
+                    // write result now
+                    float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    *(float4*)(F.irradiance + 4 * pidx) = o4;
+                    *(float4*)(F.tiles_out + 4 * (size_t)lidx) = o4;
+                    active = false;
+                }
+            } else {
+                // ---- a bounce ray returned: mcpg.comp:141-189 ----------------------------------
+                Hit next; next.wi = rd; next.pos = ro; next.prev_pos = ro; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
+                f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
+                shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
+                f3 lc_incident;
+                if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
+                else { lc_incident = rh3(throughput * light_cache_get(P, U, F.lc, rng, next.pos, next.normal)); if (COUNT) ctr.lc++; }
+                thr = thr * bsdf;
+                if (P.use_light_cache_tail) fval = thr * (seg < P.max_path_length - 1 ? incident : lc_incident);
+                else fval = thr * incident;
+                pp *= wo_p;
+                thr = thr * throughput;
+                if (GUIDED) { // mcpg.comp:165-181
+                    float mc_f = luminance((lc_incident * bsdf) * (1.0f / wo_p));
+                    if (mfinite(mc_f)) {
+                        float den = P.quirk_lc_max_wo_p ? mmax(wo_p, 10.0f) : mmax(wo_p, 1e-6f);
+                        light_cache_update(P, U, F.lc, rng, cur.pos, cur.normal, ((lc_incident * (cur.albedo * MQ_INV_PI)) * wodotn) * (1.0f / den), ctr);
+                        if (COUNT) ctr.lc++;
+                        if (xorshift(rng) * score_sum < mc_f * (float)P.mc_samples) {
+                            // mc_state_add_sample + send_update_to_buffer, mc.glsl:159-222
+                            uint32_t index = mc_index;
+                            if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, rng, cur.pos, cur.normal, index, h16); }
+                            uint32_t old = atomicAdd(&F.upd_count[index], 1u);
+                            bool ok = old < MQ_MAX_UPDATES;
+                            uint32_t q = 0;
+                            if (ok) { q = atomicAdd(&F.ctrl[1], 1u); ok = q < F.queue_cap; }
+                            if (ok) {
+                                f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
+                                uint4* e = (uint4*)(F.queue + q);
+                                uint32_t prev = atomicExch(&F.upd_head[index], q + 1u);
+                                e[0] = make_uint4(__float_as_uint(cur.pos.x), __float_as_uint(cur.pos.y), __float_as_uint(cur.pos.z), __float_as_uint(mc_f));
+                                e[1] = make_uint4(__float_as_uint(next.pos.x), __float_as_uint(next.pos.y), __float_as_uint(next.pos.z), mc_id);
+                                e[2] = make_uint4(__float_as_uint(cur.normal.x), __float_as_uint(cur.normal.y), __float_as_uint(cur.normal.z), __float_as_uint(U.cl_time));
+                                e[3] = make_uint4((uint32_t)f2h(mv.x) | ((uint32_t)f2h(mv.y) << 16), (uint32_t)f2h(mv.z) | (old << 16), index, prev);
+                                ctr.upd_ok++;
+                            } else { atomicSub(&F.upd_count[index], 1u); ctr.upd_drop++; }
+                        } else if (P.mc_fast_recovery && mc_index != MQ_NIL && !(mc_f > 1e-3f * mc_sum_w) && lm_dir_ok) {
+                            F.mc[mc_index].sum_w = 0.0f; // mcpg.comp:177
+                        }
+                    }
+                }
+                thr = thr * next.albedo; // :184
+                cur = next;
+                if ((thr.x < 1e-7f && thr.y < 1e-7f && thr.z < 1e-7f) || (fval.x > 1e-7f || fval.y > 1e-7f || fval.z > 1e-7f)) sample_done = true;
+                else { seg++; if (seg < P.max_path_length) need_dir = true; else sample_done = true; }
+            }
+
+            // ---- choose the next direction / finish samples (mcpg.comp:54-137,193-210) --------
+            while (active && (need_dir || sample_done)) {
+                if (need_dir) {
+                    need_dir = false;
+                    if (COUNT) ctr.segments++;
+                    const float alpha = roughness_to_alpha(cur.roughness);
+                    f3 wo;
+                    bool rejected = false;
+                    if (!GUIDED) { // mcpg.comp:59-64
+                        float x0 = xorshift(rng), x1 = xorshift(rng), x2 = xorshift(rng);
+                        wo = bsdf_sample(cur.wi, cur.normal, alpha, x0, x1, x2);
+                        wodotn = dot(wo, cur.normal);
+                        if (wodotn <= 1e-3f || dot(wo, decode_normal(cur.enc_geonormal)) <= 1e-3f) rejected = true;
+                        else wo_p = bsdf_pdf(cur.wi, wo, cur.normal, alpha);
+                    } else { // mcpg.comp:67-137
+                        if (COUNT) ctr.guided++;
+                        float scores[MQ_MAX_MC_SAMPLES]; f3 vdir[MQ_MAX_MC_SAMPLES]; float vk[MQ_MAX_MC_SAMPLES];
+                        uint32_t bidx[MQ_MAX_MC_SAMPLES], bh16[MQ_MAX_MC_SAMPLES]; float xsel[MQ_MAX_MC_SAMPLES]; bool badapt[MQ_MAX_MC_SAMPLES];
+                        const f3 lp = smp == 0 ? cur.prev_pos : cur.pos;
+                        // all RNG draws of the K lookups are data independent: issue addresses first,
+                        // then the K independent 48-byte state loads, then run the reservoir.
+#pragma unroll
+                        for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
+                            if (i < K) {
+                                badapt[i] = xorshift(rng) < P.mc_samples_adaptive_prob;
+                                if (badapt[i]) mc_adaptive_buffer_index(P, U, rng, lp, cur.normal, bidx[i], bh16[i]);
+                                else mc_static_buffer_index(P, rng, lp, bidx[i], bh16[i]);
+                                xsel[i] = xorshift(rng);
+                            }
+                        }
+                        score_sum = 0.0f; mc_index = MQ_NIL; mc_id = 0; mc_sum_w = 0.0f;
+                        MCS sel = {};
+#pragma unroll
+                        for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
+                            if (i < K) {
+                                MCS st = mc_load(F.mc, bidx[i]);
+                                if (COUNT) ctr.mc_reads++;
+                                mc_finalize_load(U, st, bh16[i], !badapt[i], cur.pos, cur.normal);
+                                score_sum += st.sum_w;
+                                f3 d = mc_state_dir(st, cur.pos); float kk = mc_state_kappa(P, st, cur.pos);
+                                if (xsel[i] < st.sum_w / score_sum) {
+                                    sel = st; mc_index = bidx[i];
+                                    vdir[i] = vdir[0]; vk[i] = vk[0]; scores[i] = scores[0];
+                                    scores[0] = st.sum_w; vdir[0] = d; vk[0] = kk;
+                                } else { scores[i] = st.sum_w; vdir[i] = d; vk[i] = kk; }
+                            }
+                        }
+                        if (score_sum == 0.0f || xorshift(rng) < P.surf_bsdf_p) { // :113-117
+                            float x0 = xorshift(rng), x1 = xorshift(rng), x2 = xorshift(rng);
+                            wo = bsdf_sample(cur.wi, cur.normal, alpha, x0, x1, x2);
+                            sel = mc_state_new(rng);
+                            mc_index = MQ_NIL;
+                        } else {
+                            float x0 = xorshift(rng), x1 = xorshift(rng);
+                            wo = vmf_sample(vdir[0], vk[0], x0, x1);
+                        }
+                        wodotn = dot(wo, cur.normal);
+                        if (wodotn <= 1e-3f || dot(wo, decode_normal(cur.enc_geonormal)) <= 1e-3f) rejected = true;
+                        else {
+                            float g = 0.0f;
+                            if (score_sum > 0.0f) {
+#pragma unroll
+                                for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) if (i < K) g += scores[i] * vmf_pdf(wo, vdir[i], vk[i]);
+                                g /= score_sum;
+                            }
+                            wo_p = (score_sum > 0.0f ? P.surf_bsdf_p : 1.0f) * bsdf_pdf(cur.wi, wo, cur.normal, alpha) + (1.0f - P.surf_bsdf_p) * g;
+                            mc_id = sel.id; mc_sum_w = sel.sum_w;
+                            // second half of mc_light_missing (mc.glsl:34-38), evaluated now so the state need not stay live
+                            lm_dir_ok = false;
+                            if (mc_index != MQ_NIL) lm_dir_ok = !(dot(wo, mc_state_dir(sel, cur.pos)) < 0.9f + 0.1f * mc_state_mean_cos(P, sel, cur.pos));
+                        }
+                    }
+                    if (rejected) sample_done = true; // `break` at mcpg.comp:63 / :125
+                    else {
+                        bsdf = bsdf_times_wodotn(cur.wi, wo, cur.normal, alpha, 0.02f); // :153 (depends on pre-trace data only)
+                        ro = cur.pos - cur.wi * 1e-3f; // :144
+                        rd = wo;
+                    }
+                }
+                if (sample_done) { // mcpg.comp:193-198
+                    sample_done = false;
+                    f3 contrib = fval * (1.0f / pp);
+                    if (mfinite(contrib.x) && mfinite(contrib.y) && mfinite(contrib.z)) { irr = irr + contrib; float l = luminance(contrib); m2 += l * l; }
+                    smp++;
+                    if (smp < P.spp) {
+                        load_chit(F.hits + 10 * pidx, cur);
+                        thr = F3(1, 1, 1); fval = F3(0, 0, 0); pp = 1.0f; seg = 1;
+                        need_dir = true;
+                    } else { // :205-210
+                        float inv = 1.0f / (float)P.spp;
+                        float4 o4 = make_float4(irr.x * inv, irr.y * inv, irr.z * inv, m2 * inv);
+                        *(float4*)(F.irradiance + 4 * pidx) = o4;
+                        *(float4*)(F.tiles_out + 4 * (size_t)lidx) = o4;
+                        active = false;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT || GUIDED) flush_counters(F.counters, ctr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// update application: compute_updates.comp:41-124 over the compact queue
+// ------------------------------------------------------------------------------------------------
+MQ_DEV void mc_update(MCS& s, f3 pos, float w, f3 target, const uint16_t* mv) { // :41-54
+    s.N = s.N + 1 < MQ_ML_MAX_N ? s.N + 1 : MQ_ML_MAX_N;
+    float alpha = mmax(1.0f / (float)s.N, MQ_ML_MIN_ALPHA);
+    s.sum_w = mmix(s.sum_w, w, alpha);
+    s.w_tgt = F3(mmix(s.w_tgt.x, w * target.x, alpha), mmix(s.w_tgt.y, w * target.y, alpha), mmix(s.w_tgt.z, w * target.z, alpha));
+    float co = mmax(0.0f, dot(normalize(target - pos), mc_state_dir(s, pos)));
+    s.w_cos = mmin(mmix(s.w_cos, w * co, alpha), s.sum_w);
+    s.mv[0] = mv[0]; s.mv[1] = mv[1]; s.mv[2] = mv[2];
+}
+
+__global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
+    const mq_uniform& U = F.u;
+    uint32_t n = F.ctrl[1] < F.queue_cap ? F.ctrl[1] : F.queue_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint4* e = (const uint4*)(F.queue + i);
+        uint4 e3 = e[3];
+        uint32_t slot = e3.z;
+        // the newest entry of a slot leads: it owns the whole chain of that slot
+        if (*(volatile uint32_t*)&F.upd_head[slot] != i + 1u) continue;
+        uint32_t chain[MQ_MAX_UPDATES];
+        uint32_t count = 0, at = i + 1u;
+        while (at != 0u && count < MQ_MAX_UPDATES) { chain[count++] = at - 1u; at = ((const uint4*)(F.queue + (at - 1u)))[3].w; }
+        uint32_t rng = pcg4d16(slot, 0u, U.frame, P.seed); // :62
+        MCS mc_state = mc_load(F.mc, slot);
+        float sum = 0.0f, upd_T = 0.0f;
+        f3 pos = F3(0, 0, 0), normal = F3(0, 0, 0);
+        MCS new_state = {}; bool picked = false;
+        for (uint32_t k = 0; k < count; k++) { // arrival order = reverse chain order
+            const uint4* q = (const uint4*)(F.queue + chain[count - 1u - k]);
+            uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            f3 upos = F3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            f3 utgt = F3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+            uint16_t mv[3] = {(uint16_t)(q3.x & 0xffffu), (uint16_t)(q3.x >> 16), (uint16_t)(q3.y & 0xffffu)};
+            if (k == 0) upd_T = __uint_as_float(q2.w);
+            MCS st = mc_state;
+            if (mc_state.id != q1.w) st = mc_state_new(rng);
+            mc_update(st, upos, __uint_as_float(q0.w), utgt, mv);
+            if (mc_state.id == st.id) mc_state = st;
+            sum += st.sum_w;
+            if (xorshift(rng) < st.sum_w / sum) { new_state = st; pos = upos; normal = F3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)); picked = true; }
+        }
+        new_state.T = upd_T;
+        if (picked) for (uint32_t k = 0; k < count; k++) { // :94-119
+            { uint32_t bi, h16; mc_static_buffer_index(P, rng, pos, bi, h16);
+              new_state.hash = h16; MCS old = mc_load(F.mc, bi);
+              if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
+            { uint32_t bi, h16; mc_adaptive_buffer_index(P, U, rng, pos, normal, bi, h16);
+              new_state.hash = h16; MCS old = mc_load(F.mc, bi);
+              if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
+        }
+        F.upd_count[slot] = 0u; // :121-122
+        F.upd_head[slot] = 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void mq_clear_kernel(MqFrame F) { // clear.comp:15-23, gbuffer.comp:83-90
+    size_t n = (size_t)F.W * F.H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        *(float4*)(F.irradiance + 4 * i) = make_float4(0, 0, 0, 0);
+        *(uint2*)(F.gb_albedo + 4 * i) = make_uint2(0, 0);
+        *(uint2*)(F.gb_irr + 4 * i) = make_uint2(0, 0);
+        *(uint32_t*)(F.gb_mv + 2 * i) = 0;
+        *(uint4*)(F.gbuffer + 4 * i) = make_uint4(0, 0, 0, 0);
+    }
+    size_t nt = (size_t)F.n_local_tiles * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (size_t)gridDim.x * blockDim.x)
+        *(float4*)(F.tiles_out + 4 * i) = make_float4(0, 0, 0, 0);
+}
+
+// gathered: [rank][local tile][64 px][4] -> image
+__global__ void mq_untile_kernel(const float4* gathered, float4* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank) {
+    size_t n = (size_t)n_tiles * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t gtile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63);
+        uint32_t r = gtile % world, lt = gtile / world;
+        uint32_t x = (gtile % tiles_x) * 8 + (within & 7), y = (gtile / tiles_x) * 8 + (within >> 3);
+        if (x < W && y < H) image[(size_t)y * W + x] = gathered[((size_t)r * tiles_per_rank + lt) * 64 + within];
+    }
+}
+
+__global__ __launch_bounds__(MQ_BLOCK) void mq_trace_kernel(MqSceneDev sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t_out, float* uv, unsigned long long* spill_base) {
+    __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
+    uint32_t gid = blockIdx.x * MQ_BLOCK + threadIdx.x;
+    uint2* stk = &s_stack[threadIdx.x >> 6][0][threadIdx.x & 63];
+    Ctr ctr = {};
+    for (uint32_t i = gid; i < n; i += gridDim.x * MQ_BLOCK) {
+        RayHit h;
+        traverse<false>(sc, F3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), F3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), MQ_T_MAX, h, stk, spill_base + (size_t)gid * MQ_SPILL_ENTRIES, ctr);
+        prim[i] = h.tri == MQ_NIL ? MQ_NIL : sc.tris[h.tri].key;
+        t_out[i] = h.tri == MQ_NIL ? MQ_T_MAX : h.t;
+        if (uv) { uv[2 * i] = h.u; uv[2 * i + 1] = h.v; }
+    }
+}
+
+// op codes mirror oracle/mq_oracle.h ORC_OP_* (tests map them one to one)
+__global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no, const float* in, float* out, uint32_t n) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* a = in + (size_t)k * ni; float* o = out + (size_t)k * no;
+    switch (op) {
+    case 0: o[0] = mq_exp2(a[0]); break;
+    case 1: o[0] = mq_log2(a[0]); break;
+    case 2: mq_sincos2pi(a[0], o[0], o[1]); break;
+    case 3: o[0] = mq_pow(a[0], a[1]); break;
+    case 4: o[0] = rh(a[0]); break;
+    case 5: { uint32_t e = encode_normal(F3(a[0], a[1], a[2])); f3 d = decode_normal(e); o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = __uint_as_float(e); break; }
+    case 6: { f3 wi = F3(a[0], a[1], a[2]), nn = F3(a[3], a[4], a[5]); float al = roughness_to_alpha(a[6]);
+        f3 wo = bsdf_sample(wi, nn, al, a[7], a[8], a[9]);
+        o[0] = wo.x; o[1] = wo.y; o[2] = wo.z; o[3] = bsdf_pdf(wi, wo, nn, al); o[4] = bsdf_times_wodotn(wi, wo, nn, al, 0.02f); break; }
+    case 7: { f3 mu = F3(a[0], a[1], a[2]); f3 w = vmf_sample(mu, a[3], a[4], a[5]); o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = vmf_pdf(w, mu, a[3]); break; }
+    case 8: { uint32_t s = __float_as_uint(a[0]); for (int i = 0; i < 4; i++) o[i] = xorshift(s); break; }
+    case 9: o[0] = __uint_as_float(pcg4d16(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]))); break;
+    case 10: { mq_uniform U = {}; U.sky_lf_ft = 0xfffe; U.sky_rt_bk = 0xffffffffu; U.sky_up_dn = 0xffffffffu;
+        f3 s = get_sky(sc, P, U, F3(a[0], a[1], a[2]), F3(P.sun_color[0], P.sun_color[1], P.sun_color[2])); o[0] = s.x; o[1] = s.y; o[2] = s.z; break; }
+    case 11: { i3 g = grid_idx_interpolate(F3(a[0], a[1], a[2]), a[7], 0.5f); uint32_t lv = (uint32_t)a[6];
+        o[0] = __uint_as_float(hash_grid_normal_level(g, F3(a[3], a[4], a[5]), lv, __float_as_uint(a[8]))); o[1] = __uint_as_float(hash2_grid_level(g, lv)); break; }
+    case 12: { f3 r = ldr_to_hdr(F3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+    case 13: { f3 fwd = F3(a[4], a[5], a[6]), up = F3(a[7], a[8], a[9]);
+        f3 d = camera_ray_dir(a[0], a[1], a[2], a[3], up, fwd, a[10]); o[0] = d.x; o[1] = d.y; o[2] = d.z;
+        camera_pixel(d, a[2], a[3], up, fwd, a[10], o[3], o[4]); break; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers (C++ linkage; used by mq_api.cpp)
+// ------------------------------------------------------------------------------------------------
+int mq_launch_render(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s) {
+    if (guided) { if (count) mq_render_kernel<true, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_render_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
+    else { if (count) mq_render_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_render_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
+    return (int)hipGetLastError();
+}
+int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
+    mq_apply_kernel<<<grid, 256, 0, s>>>(P, F);
+    return (int)hipGetLastError();
+}
+int mq_launch_clear(const MqFrame& F, hipStream_t s) {
+    mq_clear_kernel<<<1024, 256, 0, s>>>(F);
+    return (int)hipGetLastError();
+}
+int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s) {
+    mq_untile_kernel<<<1024, 256, 0, s>>>((const float4*)gathered, (float4*)image, W, H, tiles_x, n_tiles, world, tiles_per_rank);
+    return (int)hipGetLastError();
+}
+int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s) {
+    mq_trace_kernel<<<grid, MQ_BLOCK, 0, s>>>(sc, org, dir, n, prim, t, uv, spill);
+    return (int)hipGetLastError();
+}
+int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int no, const float* in, float* out, uint32_t n, hipStream_t s) {
+    mq_math_kernel<<<(n + 255) / 256, 256, 0, s>>>(sc, P, op, ni, no, in, out, n);
+    return (int)hipGetLastError();
+}
+int mq_render_blocks_per_cu(bool guided, bool count) {
+    int n = 0;
+    hipError_t e;
+    if (guided) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<true, true>, MQ_BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<true, false>, MQ_BLOCK, 0);
+    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<false, true>, MQ_BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<false, false>, MQ_BLOCK, 0);
+    return e == hipSuccess ? n : 0;
+}
+int mq_render_block_size() { return MQ_BLOCK; }
+int mq_spill_entries() { return MQ_SPILL_ENTRIES; }

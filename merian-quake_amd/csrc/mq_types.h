@@ -1,0 +1,167 @@
+// mq_types.h -- POD layouts shared by the host code and the HIP kernels of libmqhip.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/mq.h"
+
+#define MQ_T_MAX 10000.0f          // res/shader/config.h:11
+#define MQ_ALPHA_THRESHOLD 0.666f  // res/shader/config.h:13
+#define MQ_MAT_FLAGS_TELE 3        // res/shader/config.h:26-35
+#define MQ_MAT_FLAGS_WATER 4
+#define MQ_MAT_FLAGS_SKY 5
+#define MQ_MAT_FLAGS_WATERFALL 6
+#define MQ_MAT_FLAGS_SPRITE 7
+#define MQ_MAT_FLAGS_SOLID 8
+#define MQ_ML_MAX_N 1024           // res/shader/render_mcpg/mc.glsl:2
+#define MQ_ML_MIN_ALPHA 0.01f      // mc.glsl:3
+#define MQ_LC_MAX_N 128            // light_cache.glsl:1
+#define MQ_LC_MIN_ALPHA 0.01f      // light_cache.glsl:2
+#define MQ_MAX_UPDATES 10          // grid.h:29-34
+#define MQ_MAX_MC_SAMPLES 8        // kernel register budget; reference UI allows 0..30
+#define MQ_BARY_EPS 3.814697265625e-06f
+#define MQ_NIL 0xffffffffu
+
+// 80-byte compressed 8-wide BVH node (Ylitie et al. 2017 layout).
+struct MqNode {
+    float px, py, pz;          // quantisation origin
+    uint8_t ex, ey, ez, imask; // per-axis scale exponent (biased), internal-child mask
+    uint32_t child_base;       // index of first internal child
+    uint32_t tri_base;         // index of first triangle
+    uint8_t meta[8];
+    uint8_t qlox[8], qloy[8], qloz[8];
+    uint8_t qhix[8], qhiy[8], qhiz[8];
+};
+static_assert(sizeof(MqNode) == 80, "node must be 80 bytes");
+
+// 48-byte triangle record, stored in BVH leaf order.
+struct MqTri {
+    float v0[3], v1[3], v2[3];
+    uint32_t key;   // slot << 28 | prim
+    uint32_t flags; // bit0: needs any-hit alpha test, bit1: has distinct prev_vtx
+    uint32_t pad;
+};
+static_assert(sizeof(MqTri) == 48, "triangle must be 48 bytes");
+#define MQ_TRI_ANYHIT 1u
+#define MQ_TRI_DYNAMIC 2u
+
+struct MqTexDesc {
+    uint32_t offset; // texel offset into the texel pool; MQ_NIL if the slot is empty
+    uint16_t w, h;
+    uint32_t flags;
+};
+
+// 64-byte Markov-chain state (reference MCState is 52 B scalar, grid.h:6-21; the three
+// *_change debug fields are never written by this fork and are dropped).
+struct MqMCState {
+    float w_tgt[3];
+    float sum_w;
+    float w_cos;
+    float T;
+    uint32_t id;
+    uint32_t n_hash; // N | hash << 16
+    uint16_t mv[3];
+    uint16_t pad0;
+    uint32_t pad[6];
+};
+static_assert(sizeof(MqMCState) == 64, "mc state must be 64 bytes");
+
+// 16-byte light-cache cell (reference LightCacheVertex is 24 B, grid.h:37-46; its two statistics
+// counters live in global counters instead).
+struct MqLCCell {
+    uint32_t hash;
+    uint32_t lock;
+    uint16_t irr[3];
+    uint16_t N;
+};
+static_assert(sizeof(MqLCCell) == 16, "lc cell must be 16 bytes");
+
+// 64-byte queued Markov-chain update (one element of the reference's 512-byte MCUpdate slot,
+// grid.h:23-35).  Entries of one slot are chained through `next`.
+struct MqUpdate {
+    float pos[3];
+    float weight;
+    float target[3];
+    uint32_t id;
+    float normal[3];
+    float T;
+    uint16_t mv[3];
+    uint16_t rank;   // arrival rank within the slot (0..9)
+    uint32_t slot;
+    uint32_t next;   // index+1 of the previously pushed entry of this slot, 0 = end
+};
+static_assert(sizeof(MqUpdate) == 64, "update must be 64 bytes");
+
+// The macro table of src/render_mcpg/render_mcpg.cpp:137-185 as a kernel parameter block.
+struct MqParams {
+    int32_t reference_mode, adaptive_grid_type, spp, max_path_length, use_light_cache_tail;
+    float fov_tan_alpha_half;
+    float sun_w[3], sun_color[3];
+    int32_t volume_spp, volume_use_light_cache;
+    float draine_g, draine_a;
+    int32_t mc_samples;
+    float mc_samples_adaptive_prob;
+    int32_t distance_mc_samples, mc_fast_recovery, lc_grid_type;
+    uint32_t lc_buffer_size;
+    float lc_grid_steps_per_unit_size, lc_grid_tan_alpha_half, lc_grid_min_width, lc_grid_power;
+    uint32_t mc_adaptive_buffer_size;
+    float mc_adaptive_grid_tan_alpha_half, mc_adaptive_grid_min_width, mc_adaptive_grid_power,
+        mc_adaptive_grid_steps_per_unit_size;
+    uint32_t mc_static_buffer_size;
+    float mc_static_grid_width;
+    int32_t distance_mc_grid_width;
+    float volume_max_t, surf_bsdf_p, volume_phase_p, dir_guide_prior, dist_guide_p;
+    uint32_t distance_mc_vertex_state_count, seed;
+    int32_t gbuffer_hide_sun, quirk_lc_max_wo_p, quirk_n16_wrap;
+    int32_t debug_output_selector;
+};
+
+struct MqGeoDev {
+    const mq_ext* ext;
+    const uint32_t* idx;
+    const float* prev_vtx;
+};
+
+// Everything a kernel needs to see the scene.
+struct MqSceneDev {
+    const MqNode* nodes;
+    const MqTri* tris;
+    MqGeoDev geo[MQ_MAX_GEOMETRIES];
+    const MqTexDesc* tex;
+    const uint32_t* texels;
+    const float* srgb_lut; // 256 entries
+    uint32_t n_nodes, n_tris;
+};
+
+struct MqCountersDev {
+    unsigned long long rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
+        mc_updates_dropped, mc_state_reads, pixels, lc_ok, lc_cancel;
+};
+
+// Per-frame launch block of the render kernel.
+struct MqFrame {
+    mq_uniform u;
+    uint32_t W, H;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_local_tiles; // tiles this rank renders
+    uint32_t rank, world;
+    // outputs
+    float* irradiance;     // W*H*4 (full image, linear index) -- written for local tiles only
+    float* tiles_out;      // n_local_tiles*64*4
+    uint16_t* gb_albedo;   // W*H*4 half
+    uint16_t* gb_irr;      // W*H*4 half
+    uint16_t* gb_mv;       // W*H*2 half
+    uint32_t* gbuffer;     // W*H*4 dwords
+    uint32_t* hits;        // W*H*10 dwords
+    // learning state
+    MqMCState* mc;
+    MqLCCell* lc;
+    uint32_t* upd_count;   // per mc slot
+    uint32_t* upd_head;    // per mc slot, index+1 of the newest queue entry
+    MqUpdate* queue;
+    uint32_t queue_cap;
+    // control words: [0] next pixel, [1] queue tail
+    uint32_t* ctrl;
+    MqCountersDev* counters;
+    // traversal stack spill area: MQ_SPILL_ENTRIES 8-byte entries per resident lane
+    unsigned long long* stack_spill;
+};

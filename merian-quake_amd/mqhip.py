@@ -1,0 +1,304 @@
+"""ctypes binding of libmqhip.so (include/mq.h) -- plumbing for tests and bench.py.
+
+The product is the C ABI; this file adds nothing but argument marshalling.  It mirrors the
+reference's node lifecycle (describe -> connect -> process -> properties,
+src/render_mcpg/render_mcpg.hpp:36-49) one call per method.  There is no CPU rendering path: if
+the HIP extension cannot be loaded, import fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmqhip.so")
+
+MQ_MAX_GLTEXTURES = 4096
+MQ_MAX_GEOMETRIES = 16
+MQ_GEO_OPAQUE, MQ_GEO_STATIC = 1, 2
+MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
+(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_COUNT) = range(8)
+MQ_ENODEVICE = -2
+
+EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),
+                      ("n1_brush", "<u4"), ("n2", "<u4"), ("st", "<u2", (6,))])
+assert EXT_DTYPE.itemsize == 28
+
+
+class Uniform(C.Structure):
+    _fields_ = [("cam_x", C.c_float * 4), ("cam_w", C.c_float * 4), ("cam_u", C.c_float * 4),
+                ("prev_cam_x", C.c_float * 4), ("prev_cam_w", C.c_float * 4), ("prev_cam_u", C.c_float * 4),
+                ("sky_rt_bk", C.c_uint32), ("sky_lf_ft", C.c_uint32), ("sky_up_dn", C.c_uint32),
+                ("cl_time", C.c_float), ("frame", C.c_uint32), ("player", C.c_uint32), ("rt_config", C.c_uint32)]
+
+
+assert C.sizeof(Uniform) == 124
+
+
+class Constants(C.Structure):
+    _fields_ = [("sun_color", C.c_float * 3), ("sun_direction", C.c_float * 3), ("fov", C.c_float),
+                ("fov_tan_alpha_half", C.c_float), ("volume_max_t", C.c_float)]
+
+
+class IoDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bytes", C.c_size_t * OUT_COUNT),
+                ("bytes_per_pixel", C.c_uint32 * OUT_COUNT), ("state_bytes_markovchain", C.c_size_t),
+                ("state_bytes_lightcache", C.c_size_t), ("state_bytes_update_queue", C.c_size_t)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "tris", "segments", "guided_segments", "lc_touches",
+                                          "mc_updates_accepted", "mc_updates_dropped", "mc_state_reads", "pixels")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class MqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mq error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("libmqhip.so not built (%s): run __graft_entry__.build() or `make -C merian-quake_amd`" % path)
+    lib = C.CDLL(path)
+    P, u32, i32, f32p, u32p, vp, sz = C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t
+    sigs = {
+        "mq_abi_version": (i32, []),
+        "mq_create": (i32, [C.POINTER(P), i32]),
+        "mq_destroy": (None, [P]),
+        "mq_last_error": (C.c_char_p, [P]),
+        "mq_set_property": (i32, [P, C.c_char_p, C.c_double]),
+        "mq_set_property_str": (i32, [P, C.c_char_p, C.c_char_p]),
+        "mq_get_property": (i32, [P, C.c_char_p, C.POINTER(C.c_double)]),
+        "mq_property_count": (i32, []),
+        "mq_property_name": (C.c_char_p, [i32]),
+        "mq_load_properties_json": (i32, [P, C.c_char_p, C.c_char_p]),
+        "mq_properties_header_defaults": (None, [P]),
+        "mq_properties_json_defaults": (None, [P]),
+        "mq_scene_set_geometry": (i32, [P, i32, vp, vp, u32, vp, vp, u32, u32]),
+        "mq_scene_set_texture": (i32, [P, u32, u32, u32, vp, u32]),
+        "mq_scene_commit": (i32, [P]),
+        "mq_set_constants": (i32, [P, C.POINTER(Constants)]),
+        "mq_get_constants": (i32, [P, C.POINTER(Constants)]),
+        "mq_scene_get_geometry": (i32, [P, i32, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(vp), C.POINTER(vp), u32p, u32p]),
+        "mq_scene_get_texture": (i32, [P, u32, u32p, u32p, C.POINTER(vp), u32p]),
+        "mq_scene_stats": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]),
+        "mq_describe": (i32, [P, u32, u32, C.POINTER(IoDesc)]),
+        "mq_connect": (i32, [P, u32, u32]),
+        "mq_process": (i32, [P, C.POINTER(Uniform), i32, vp]),
+        "mq_sync": (i32, [P]),
+        "mq_map_output": (i32, [P, i32, C.POINTER(vp), C.POINTER(sz)]),
+        "mq_read_output": (i32, [P, i32, vp, sz]),
+        "mq_last_frame_ms": (i32, [P, f32p, f32p, f32p]),
+        "mq_enable_counters": (i32, [P, i32]),
+        "mq_get_counters": (i32, [P, C.POINTER(Counters)]),
+        "mq_reset_state": (i32, [P]),
+        "mq_set_partition": (i32, [P, i32, i32]),
+        "mq_tiles_per_rank": (i32, [P, u32p, C.POINTER(sz)]),
+        "mq_untile": (i32, [P, vp, vp]),
+        "mq_trace_rays": (i32, [P, vp, vp, u32, vp, vp, vp]),
+        "mq_math_eval": (i32, [P, i32, vp, vp, u32]),
+        "mq_synth_scene": (i32, [P, C.c_char_p, u32]),
+        "mq_synth_camera": (i32, [P, u32, C.POINTER(Uniform)]),
+        "mq_load_bsp": (i32, [P, C.c_char_p, C.c_char_p]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    lib._mq_symbols = sorted(sigs)
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One render node instance (GBuffer + Renderer (MCPG)) on one HIP device, or host-only (device=-1)."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or load_library()
+        self.h = C.c_void_p()
+        r = self.lib.mq_create(C.byref(self.h), device)
+        if r != 0:
+            raise MqError(r, "mq_create(device=%d) failed%s" % (device, " (no HIP device)" if r == MQ_ENODEVICE else ""))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.mq_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r < 0:
+            raise MqError(r, (self.lib.mq_last_error(self.h) or b"").decode())
+        return r
+
+    # -- properties()
+    def set_property(self, key, value):
+        if isinstance(value, str):
+            return self._chk(self.lib.mq_set_property_str(self.h, key.encode(), value.encode()))
+        return self._chk(self.lib.mq_set_property(self.h, key.encode(), float(value)))
+
+    def get_property(self, key):
+        v = C.c_double()
+        self._chk(self.lib.mq_get_property(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def property_names(self):
+        return [self.lib.mq_property_name(i).decode() for i in range(self.lib.mq_property_count())]
+
+    def load_properties_json(self, text, node):
+        return self._chk(self.lib.mq_load_properties_json(self.h, text.encode(), node.encode()))
+
+    def header_defaults(self):
+        self.lib.mq_properties_header_defaults(self.h)
+
+    def json_defaults(self):
+        self.lib.mq_properties_json_defaults(self.h)
+
+    # -- scene
+    def set_geometry(self, slot, vtx, prev_vtx, idx, ext, flags):
+        vtx = np.ascontiguousarray(vtx, np.float32).reshape(-1, 3)
+        prev = None if prev_vtx is None else np.ascontiguousarray(prev_vtx, np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+        ext = np.ascontiguousarray(ext, EXT_DTYPE)
+        assert len(ext) == len(idx)
+        self._chk(self.lib.mq_scene_set_geometry(self.h, slot, _ptr(vtx), _ptr(prev), len(vtx), _ptr(idx), _ptr(ext), len(idx), flags))
+
+    def set_texture(self, texnum, rgba8, flags):
+        rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+        h, w = rgba8.shape[:2]
+        self._chk(self.lib.mq_scene_set_texture(self.h, texnum, w, h, _ptr(rgba8), flags))
+
+    def commit(self):
+        self._chk(self.lib.mq_scene_commit(self.h))
+
+    def set_constants(self, sun_color, sun_direction, fov=90.0, fov_tan_alpha_half=1.0, volume_max_t=1000.0):
+        c = Constants((C.c_float * 3)(*sun_color), (C.c_float * 3)(*sun_direction), fov, fov_tan_alpha_half, volume_max_t)
+        self._chk(self.lib.mq_set_constants(self.h, C.byref(c)))
+
+    def get_constants(self):
+        c = Constants()
+        self._chk(self.lib.mq_get_constants(self.h, C.byref(c)))
+        return dict(sun_color=list(c.sun_color), sun_direction=list(c.sun_direction), fov=c.fov,
+                    fov_tan_alpha_half=c.fov_tan_alpha_half, volume_max_t=c.volume_max_t)
+
+    def get_geometry(self, slot):
+        vtx, prev, idx, ext = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nv, nt, fl = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.lib.mq_scene_get_geometry(self.h, slot, C.byref(vtx), C.byref(prev), C.byref(nv), C.byref(idx), C.byref(ext), C.byref(nt), C.byref(fl)))
+        if nt.value == 0:
+            return None
+
+        def arr(p, n, dt):
+            return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(p.value), dtype=dt).copy()
+        return dict(vtx=arr(vtx, nv.value * 3, np.float32).reshape(-1, 3), prev_vtx=arr(prev, nv.value * 3, np.float32).reshape(-1, 3),
+                    idx=arr(idx, nt.value * 3, np.uint32).reshape(-1, 3), ext=arr(ext, nt.value, EXT_DTYPE), flags=fl.value)
+
+    def get_texture(self, texnum):
+        w, h, fl, p = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_void_p()
+        self._chk(self.lib.mq_scene_get_texture(self.h, texnum, C.byref(w), C.byref(h), C.byref(p), C.byref(fl)))
+        if not p.value:
+            return None
+        px = np.frombuffer((C.c_char * (w.value * h.value * 4)).from_address(p.value), dtype=np.uint8).copy().reshape(h.value, w.value, 4)
+        return px, fl.value
+
+    def scene_stats(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        s = C.c_float()
+        self._chk(self.lib.mq_scene_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(s)))
+        return dict(n_tris=a.value, n_nodes=b.value, bvh_bytes=c.value, sah_cost=s.value)
+
+    def synth_scene(self, name, seed=1):
+        self._chk(self.lib.mq_synth_scene(self.h, name.encode(), seed))
+
+    def synth_camera(self, frame):
+        u = Uniform()
+        self._chk(self.lib.mq_synth_camera(self.h, frame, C.byref(u)))
+        return u
+
+    def load_bsp(self, path, palette=None):
+        self._chk(self.lib.mq_load_bsp(self.h, path.encode(), palette.encode() if palette else None))
+
+    # -- describe / connect / process
+    def describe(self, w, h):
+        d = IoDesc()
+        self._chk(self.lib.mq_describe(self.h, w, h, C.byref(d)))
+        return d
+
+    def connect(self, w, h):
+        self._chk(self.lib.mq_connect(self.h, w, h))
+        self.W, self.H = w, h
+
+    def process(self, uniform, render=True, stream=None):
+        self._chk(self.lib.mq_process(self.h, C.byref(uniform), 1 if render else 0, stream))
+
+    def sync(self):
+        self._chk(self.lib.mq_sync(self.h))
+
+    def map_output(self, which):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.mq_map_output(self.h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_output(self, which):
+        _, n = self.map_output(which)
+        buf = np.empty(n, np.uint8)
+        self._chk(self.lib.mq_read_output(self.h, which, _ptr(buf), n))
+        return buf
+
+    def irradiance(self):
+        return self.read_output(OUT_IRRADIANCE).view(np.float32).reshape(self.H, self.W, 4)
+
+    def last_frame_ms(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        self._chk(self.lib.mq_last_frame_ms(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def enable_counters(self, on):
+        self._chk(self.lib.mq_enable_counters(self.h, 1 if on else 0))
+
+    def counters(self):
+        c = Counters()
+        self._chk(self.lib.mq_get_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_state(self):
+        self._chk(self.lib.mq_reset_state(self.h))
+
+    def set_partition(self, rank, world):
+        self._chk(self.lib.mq_set_partition(self.h, rank, world))
+
+    def tiles_per_rank(self):
+        t, b = C.c_uint32(), C.c_size_t()
+        self._chk(self.lib.mq_tiles_per_rank(self.h, C.byref(t), C.byref(b)))
+        return t.value, b.value
+
+    def untile(self, gathered_dev_ptr, stream=None):
+        self._chk(self.lib.mq_untile(self.h, gathered_dev_ptr, stream))
+
+    def trace_rays(self, org, direction):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, np.float32).reshape(-1, 3)
+        n = len(org)
+        prim, t, uv = np.empty(n, np.uint32), np.empty(n, np.float32), np.empty((n, 2), np.float32)
+        self._chk(self.lib.mq_trace_rays(self.h, _ptr(org), _ptr(direction), n, _ptr(prim), _ptr(t), _ptr(uv)))
+        return prim, t, uv
+
+    def math_eval(self, op, inp, n_out):
+        inp = np.ascontiguousarray(inp, np.float32)
+        n = inp.shape[0]
+        out = np.empty((n, n_out), np.float32)
+        self._chk(self.lib.mq_math_eval(self.h, op, _ptr(inp), _ptr(out), n))
+        return out

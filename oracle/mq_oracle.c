@@ -1,0 +1,1005 @@
+/*
+ * mq_oracle.c -- CPU ORACLE (test infrastructure; see mq_oracle.h for the rules and the
+ * "parity unpinned" statement).  A plain-C restatement of the reference's hot path:
+ *
+ *   g-buffer first hit   res/shader/gbuffer/gbuffer.comp:75-131
+ *   trace_ray + any-hit  res/shader/raytrace.glsl:25-65,82-119,156-311
+ *   hit (de)compression  res/shader/hit.glsl.h:34-53
+ *   surface estimator    res/shader/render_mcpg/mcpg.comp:39-210
+ *   Markov-chain states  res/shader/render_mcpg/mc.glsl:17-222, grid.h:6-35
+ *   light cache          res/shader/render_mcpg/light_cache.glsl:13-84
+ *   update application   res/shader/render_mcpg/compute_updates.comp:41-124
+ *   pass order           src/render_mcpg/render_mcpg.cpp:221-277
+ *
+ * Traversal is deliberately naive: brute force over all triangles, or a plain binary
+ * median-split BVH.  Both return the identical closest hit (smallest t, ties -> smallest
+ * (slot, prim) key).
+ */
+#define _GNU_SOURCE
+#include "mq_oracle.h"
+#include "orc_math.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define T_MAX 10000.0f          /* res/shader/config.h:11 */
+#define ALPHA_THRESHOLD 0.666f  /* res/shader/config.h:13 */
+#define MAX_GLTEXTURES 4096     /* res/shader/config.h:5 */
+#define MAX_GEOMETRIES 16       /* res/shader/config.h:6 */
+#define MAT_FLAGS_WATER 4
+#define MAT_FLAGS_SKY 5
+#define MAT_FLAGS_WATERFALL 6
+#define MAT_FLAGS_SPRITE 7
+#define MAT_FLAGS_TELE 3
+#define MAT_FLAGS_SOLID 8
+#define ML_MAX_N 1024           /* mc.glsl:2 */
+#define ML_MIN_ALPHA 0.01f      /* mc.glsl:3 */
+#define LIGHT_CACHE_MAX_N 128   /* light_cache.glsl:1 */
+#define LIGHT_CACHE_MIN_ALPHA 0.01f
+#define MAX_UPDATES 10          /* grid.h:29-34 */
+#define BARY_EPS 3.814697265625e-06f /* 2^-18: closes cracks between adjacent triangles */
+
+/* ---------------------------------------------------------------- data */
+
+typedef struct {
+    float* vtx; float* prev_vtx; uint32_t n_vtx;
+    uint32_t* idx; orc_ext_t* ext; uint32_t n_tri; uint32_t flags;
+} geo_t;
+
+typedef struct { uint32_t w, h, flags; uint8_t* px; } tex_t;
+
+typedef struct { v3 v0, v1, v2; uint32_t key; uint32_t opaque; } tri_t;
+typedef struct { v3 bmin, bmax; uint32_t left, count; } bnode_t; /* count>0: leaf [left,left+count) */
+
+/* grid.h:6-21 */
+typedef struct {
+    uint32_t id; float tgt_change, w_change, cos_change;
+    v3 w_tgt; float sum_w, w_cos;
+    uint16_t mv[3]; float T; uint16_t N; uint16_t hash;
+} mcstate_t;
+/* grid.h:23-35 (the reference stores one per state slot; the oracle keeps them sparsely) */
+typedef struct {
+    float T; uint16_t mv[MAX_UPDATES][3]; uint32_t ids[MAX_UPDATES]; float weights[MAX_UPDATES];
+    v3 targets[MAX_UPDATES], positions[MAX_UPDATES], normals[MAX_UPDATES];
+} mcupdate_t;
+/* grid.h:37-46 */
+typedef struct { uint32_t hash, lock; uint16_t irr[3]; uint16_t N; uint32_t ok, cancel; } lcvertex_t;
+
+/* hit.glsl.h:6-17 */
+typedef struct { v3 pos, prev_pos, wi, normal; uint32_t enc_geonormal; v3 albedo; float roughness; } hit_t;
+/* hit.glsl.h:19-30, 40 bytes scalar layout */
+typedef struct { float pos[3]; uint16_t mv[3]; uint16_t _pad; uint32_t wi, normal, enc_geonormal; uint16_t albedo[3]; uint16_t roughness; } chit_t;
+
+typedef struct { uint32_t enc_normal; float linear_z; uint16_t grad_z[2]; float vel_z; } gbuf_t;
+
+struct orc_ctx {
+    orc_params_t p;
+    geo_t geo[MAX_GEOMETRIES];
+    tex_t* tex; /* MAX_GLTEXTURES */
+    float srgb_lut[256];
+    /* accel */
+    int accel;
+    tri_t* tris; uint32_t n_tris;
+    bnode_t* nodes; uint32_t n_nodes;
+    /* frame state */
+    uint32_t W, H;
+    orc_uniform_t u;
+    mcstate_t* mc; uint32_t mc_total;
+    lcvertex_t* lc;
+    uint32_t* upd_count; uint32_t* upd_rec; mcupdate_t* upd_pool; uint32_t upd_pool_cap; uint32_t upd_pool_used;
+    uint32_t* upd_touched; uint32_t upd_touched_n;
+    /* outputs */
+    float* irradiance; uint16_t* gb_albedo; uint16_t* gb_irr; uint16_t* gb_mv; gbuf_t* gbuffer; chit_t* hits;
+    orc_counters_t ctr;
+    int racy; /* threads > 1 in guided mode */
+};
+
+/* ---------------------------------------------------------------- params */
+
+void orc_params_header_defaults(orc_params_t* p) { /* render_mcpg.hpp:108-166, gbuffer.hpp:75-77 */
+    memset(p, 0, sizeof *p);
+    p->reference_mode = 0; p->adaptive_grid_type = 0; p->spp = 1; p->max_path_length = 3;
+    p->use_light_cache_tail = 0; p->fov_tan_alpha_half = 1.0f;
+    p->sun_w[0] = p->sun_w[1] = p->sun_w[2] = 0.57735026919f;
+    p->volume_spp = 0; p->volume_use_light_cache = 0;
+    p->mc_samples = 5; p->mc_samples_adaptive_prob = 0.7f; p->distance_mc_samples = 3; p->mc_fast_recovery = 1;
+    p->lc_grid_type = 0; p->lc_buffer_size = 4000000; p->lc_grid_steps_per_unit_size = 6.0f;
+    p->lc_grid_tan_alpha_half = 0.002f; p->lc_grid_min_width = 0.01f; p->lc_grid_power = 2.0f;
+    p->mc_adaptive_buffer_size = 32777259; p->mc_adaptive_grid_tan_alpha_half = 0.003f;
+    p->mc_adaptive_grid_min_width = 0.01f; p->mc_adaptive_grid_power = 4.0f; p->mc_adaptive_grid_steps_per_unit_size = 6.0f;
+    p->mc_static_buffer_size = 800009; p->mc_static_grid_width = 25.3f; p->distance_mc_grid_width = 25;
+    p->volume_max_t = 1000.0f; p->surf_bsdf_p = 0.15f; p->volume_phase_p = 0.3f; p->dir_guide_prior = 0.2f; p->dist_guide_p = 0.0f;
+    p->distance_mc_vertex_state_count = 10; p->seed = 0;
+    { double d = 25.0; p->draine_g = (float)exp(-2.20679 / (d + 3.91029) - 0.428934); p->draine_a = (float)exp(3.62489 - 8.29288 / (d + 5.52825)); }
+    p->gbuffer_hide_sun = 1; p->quirk_lc_max_wo_p = 1; p->quirk_n16_wrap = 0;
+}
+void orc_params_json_defaults(orc_params_t* p) { /* default_config.json:599-638 */
+    orc_params_header_defaults(p);
+    p->surf_bsdf_p = 0.1f; p->lc_buffer_size = 4000037; p->lc_grid_tan_alpha_half = 0.005f; p->lc_grid_type = 1;
+    p->dir_guide_prior = 0.3f; p->volume_phase_p = 0.1f; p->mc_adaptive_grid_power = 1.7320508f;
+    p->mc_adaptive_grid_steps_per_unit_size = 1.0f; p->mc_adaptive_grid_tan_alpha_half = 0.002f;
+    p->dist_guide_p = 0.9f; p->spp = 2; p->volume_spp = 2; p->volume_use_light_cache = 1; p->volume_max_t = 10000.0f;
+    { double d = 7.0; p->draine_g = (float)exp(-2.20679 / (d + 3.91029) - 0.428934); p->draine_a = (float)exp(3.62489 - 8.29288 / (d + 5.52825)); }
+}
+
+/* ---------------------------------------------------------------- ctx */
+
+orc_ctx* orc_create(const orc_params_t* p) {
+    orc_ctx* c = (orc_ctx*)calloc(1, sizeof *c);
+    if (!c) return NULL;
+    if (p) c->p = *p; else orc_params_header_defaults(&c->p);
+    c->tex = (tex_t*)calloc(MAX_GLTEXTURES, sizeof(tex_t));
+    for (int i = 0; i < 256; i++) { /* sRGB EOTF, evaluated in double then rounded once */
+        double v = i / 255.0;
+        double l = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4);
+        c->srgb_lut[i] = (float)l;
+    }
+    return c;
+}
+static void free_state(orc_ctx* c) {
+    free(c->mc); free(c->lc); free(c->upd_count); free(c->upd_rec); free(c->upd_pool); free(c->upd_touched);
+    free(c->irradiance); free(c->gb_albedo); free(c->gb_irr); free(c->gb_mv); free(c->gbuffer); free(c->hits);
+    c->mc = NULL; c->lc = NULL; c->upd_count = c->upd_rec = NULL; c->upd_pool = NULL; c->upd_touched = NULL;
+    c->irradiance = NULL; c->gb_albedo = c->gb_irr = c->gb_mv = NULL; c->gbuffer = NULL; c->hits = NULL;
+}
+void orc_destroy(orc_ctx* c) {
+    if (!c) return;
+    for (int i = 0; i < MAX_GEOMETRIES; i++) { free(c->geo[i].vtx); free(c->geo[i].prev_vtx); free(c->geo[i].idx); free(c->geo[i].ext); }
+    for (int i = 0; i < MAX_GLTEXTURES; i++) free(c->tex[i].px);
+    free(c->tex); free(c->tris); free(c->nodes);
+    free_state(c);
+    free(c);
+}
+int orc_set_params(orc_ctx* c, const orc_params_t* p) { c->p = *p; return 0; }
+
+static void* dup_mem(const void* src, size_t n) { void* d = malloc(n ? n : 1); if (d && src) memcpy(d, src, n); return d; }
+
+int orc_set_geometry(orc_ctx* c, int slot, const float* vtx, const float* prev_vtx, uint32_t n_vtx,
+                     const uint32_t* idx, const orc_ext_t* ext, uint32_t n_tri, uint32_t flags) {
+    if (slot < 0 || slot >= MAX_GEOMETRIES) return -1;
+    geo_t* g = &c->geo[slot];
+    free(g->vtx); free(g->prev_vtx); free(g->idx); free(g->ext);
+    memset(g, 0, sizeof *g);
+    if (n_tri == 0) return 0;
+    g->vtx = (float*)dup_mem(vtx, (size_t)n_vtx * 12);
+    g->prev_vtx = (float*)dup_mem(prev_vtx ? prev_vtx : vtx, (size_t)n_vtx * 12);
+    g->idx = (uint32_t*)dup_mem(idx, (size_t)n_tri * 12);
+    g->ext = (orc_ext_t*)dup_mem(ext, (size_t)n_tri * sizeof(orc_ext_t));
+    g->n_vtx = n_vtx; g->n_tri = n_tri; g->flags = flags;
+    for (uint32_t i = 0; i < n_tri * 3; i++) if (idx[i] >= n_vtx) return -2;
+    return 0;
+}
+int orc_set_texture(orc_ctx* c, uint32_t texnum, uint32_t w, uint32_t h, const uint8_t* rgba8, uint32_t flags) {
+    if (texnum >= MAX_GLTEXTURES) return -1;
+    tex_t* t = &c->tex[texnum];
+    free(t->px); t->px = NULL; t->w = t->h = 0;
+    if (!rgba8 || !w || !h) return 0;
+    t->px = (uint8_t*)dup_mem(rgba8, (size_t)w * h * 4);
+    t->w = w; t->h = h; t->flags = flags;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- textures */
+
+typedef struct { float r, g, b, a; } v4;
+
+static inline int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+static inline v4 texel(const orc_ctx* c, const tex_t* t, int x, int y) {
+    const uint8_t* p = t->px + 4 * ((size_t)wrapi(y, (int)t->h) * t->w + (size_t)wrapi(x, (int)t->w));
+    v4 r;
+    if (t->flags & ORC_TEX_SRGB) { r.r = c->srgb_lut[p[0]]; r.g = c->srgb_lut[p[1]]; r.b = c->srgb_lut[p[2]]; }
+    else { r.r = (float)p[0] * (1.0f / 255.0f); r.g = (float)p[1] * (1.0f / 255.0f); r.b = (float)p[2] * (1.0f / 255.0f); }
+    r.a = (float)p[3] * (1.0f / 255.0f);
+    return r;
+}
+/* textureLod(img_tex[texnum], st, 0) with REPEAT wrap; nearest or bilinear per texture.
+ * A texture slot that was never uploaded samples as opaque mid grey. */
+static v4 tex_sample(const orc_ctx* c, uint32_t texnum, float s, float t) {
+    if (texnum > MAX_GLTEXTURES - 1) texnum = MAX_GLTEXTURES - 1;
+    const tex_t* tx = &c->tex[texnum];
+    if (!tx->px) { v4 g = {0.5f, 0.5f, 0.5f, 1.0f}; return g; }
+    float fw = (float)tx->w, fh = (float)tx->h;
+    if (!(tx->flags & ORC_TEX_LINEAR)) {
+        return texel(c, tx, (int)floorf(s * fw), (int)floorf(t * fh));
+    }
+    float x = s * fw - 0.5f, y = t * fh - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    int ix = (int)x0, iy = (int)y0;
+    v4 a = texel(c, tx, ix, iy), b = texel(c, tx, ix + 1, iy), d = texel(c, tx, ix, iy + 1), e = texel(c, tx, ix + 1, iy + 1);
+    v4 r;
+    r.r = omix(omix(a.r, b.r, fx), omix(d.r, e.r, fx), fy);
+    r.g = omix(omix(a.g, b.g, fx), omix(d.g, e.g, fx), fy);
+    r.b = omix(omix(a.b, b.b, fx), omix(d.b, e.b, fx), fy);
+    r.a = omix(omix(a.a, b.a, fx), omix(d.a, e.a, fx), fy);
+    return r;
+}
+/* textureGather(tex, st, 3).r : alpha of footprint texel (i0, j0+1) */
+static float tex_gather_alpha_r(const orc_ctx* c, uint32_t texnum, float s, float t) {
+    if (texnum > MAX_GLTEXTURES - 1) texnum = MAX_GLTEXTURES - 1;
+    const tex_t* tx = &c->tex[texnum];
+    if (!tx->px) return 1.0f;
+    int ix = (int)floorf(s * (float)tx->w - 0.5f), iy = (int)floorf(t * (float)tx->h - 0.5f);
+    return texel(c, tx, ix, iy + 1).a;
+}
+
+/* ---------------------------------------------------------------- intersection */
+
+/* Moeller-Trumbore, front faces only: the geometric normal is cross(v2-v0, v1-v0)
+ * (raytrace.glsl:221-223) and a ray hits only if dot(dir, normal) < 0 (raytrace.glsl:73,85). */
+static inline int tri_isect(v3 o, v3 d, v3 v0, v3 v1, v3 v2, float* t, float* u, float* v) {
+    v3 e1 = vsub(v1, v0), e2 = vsub(v2, v0);
+    v3 pv = vcross(d, e2);
+    float det = vdot(e1, pv);
+    if (!(det < 0.0f)) return 0;
+    float inv = 1.0f / det;
+    v3 tv = vsub(o, v0);
+    float uu = vdot(tv, pv) * inv;
+    if (!(uu >= -BARY_EPS) || !(uu <= 1.0f + BARY_EPS)) return 0;
+    v3 qv = vcross(tv, e1);
+    float vv = vdot(d, qv) * inv;
+    if (!(vv >= -BARY_EPS) || !(uu + vv <= 1.0f + BARY_EPS)) return 0;
+    float tt = vdot(e2, qv) * inv;
+    if (!(tt > 0.0f)) return 0;
+    *t = tt; *u = uu; *v = vv;
+    return 1;
+}
+
+typedef struct { uint32_t key; float t, u, v; } rayhit_t;
+
+static inline const orc_ext_t* ext_of(const orc_ctx* c, uint32_t key) { return &c->geo[key >> 28].ext[key & 0x0fffffffu]; }
+
+/* any-hit confirmation, raytrace.glsl:100-118 */
+static int anyhit_confirm(const orc_ctx* c, uint32_t key, float u, float v) {
+    const orc_ext_t* e = ext_of(c, key);
+    uint32_t flags = e->texnum_fb_flags >> 12, alpha = e->texnum_alpha >> 12;
+    if (flags > 0 && flags < 7) return 1;
+    if (alpha != 0) return orc_rh((float)(alpha - 1) / 14.0f) >= ALPHA_THRESHOLD;
+    float b0 = 1.0f - u - v;
+    float s = orc_h2f(e->st[0]) * b0 + orc_h2f(e->st[2]) * u + orc_h2f(e->st[4]) * v;
+    float t = orc_h2f(e->st[1]) * b0 + orc_h2f(e->st[3]) * u + orc_h2f(e->st[5]) * v;
+    return tex_gather_alpha_r(c, e->texnum_alpha & 0xfffu, s, t) >= ALPHA_THRESHOLD;
+}
+
+static inline void consider(const orc_ctx* c, const tri_t* tr, v3 o, v3 d, float tmax, rayhit_t* best, orc_counters_t* ctr) {
+    float t, u, v;
+    ctr->tris++;
+    if (!tri_isect(o, d, tr->v0, tr->v1, tr->v2, &t, &u, &v)) return;
+    if (!(t < tmax)) return;
+    if (t < best->t || (t == best->t && tr->key < best->key)) {
+        if (!tr->opaque && !anyhit_confirm(c, tr->key, u, v)) return;
+        best->t = t; best->u = u; best->v = v; best->key = tr->key;
+    }
+}
+
+static inline int slab(const bnode_t* n, v3 o, v3 id, float tbest, float* tnear) {
+    float tx0 = (n->bmin.x - o.x) * id.x, tx1 = (n->bmax.x - o.x) * id.x;
+    float ty0 = (n->bmin.y - o.y) * id.y, ty1 = (n->bmax.y - o.y) * id.y;
+    float tz0 = (n->bmin.z - o.z) * id.z, tz1 = (n->bmax.z - o.z) * id.z;
+    float tn = omax(omax(omin(tx0, tx1), omin(ty0, ty1)), omax(omin(tz0, tz1), 0.0f));
+    float tf = omin(omin(omax(tx0, tx1), omax(ty0, ty1)), omin(omax(tz0, tz1), tbest * 1.000001f + 1e-6f));
+    *tnear = tn;
+    return tn <= tf;
+}
+
+static void closest_hit(const orc_ctx* c, v3 o, v3 d, float tmax, rayhit_t* best, orc_counters_t* ctr) {
+    best->key = 0xffffffffu; best->t = INFINITY; best->u = best->v = 0.0f;
+    ctr->rays++;
+    if (!c->accel || !c->nodes) {
+        for (uint32_t i = 0; i < c->n_tris; i++) consider(c, &c->tris[i], o, d, tmax, best, ctr);
+        return;
+    }
+    v3 id;
+    id.x = 1.0f / (fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f));
+    id.y = 1.0f / (fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f));
+    id.z = 1.0f / (fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f));
+    uint32_t stack[128]; int sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+        const bnode_t* n = &c->nodes[stack[--sp]];
+        float tn;
+        ctr->nodes++;
+        if (!slab(n, o, id, omin(best->t, tmax), &tn)) continue;
+        if (n->count) { for (uint32_t i = 0; i < n->count; i++) consider(c, &c->tris[n->left + i], o, d, tmax, best, ctr); continue; }
+        float t0, t1;
+        int h0 = slab(&c->nodes[n->left], o, id, omin(best->t, tmax), &t0);
+        int h1 = slab(&c->nodes[n->left + 1], o, id, omin(best->t, tmax), &t1);
+        if (h0 && h1) { if (t0 < t1) { stack[sp++] = n->left + 1; stack[sp++] = n->left; } else { stack[sp++] = n->left; stack[sp++] = n->left + 1; } }
+        else if (h0) stack[sp++] = n->left; else if (h1) stack[sp++] = n->left + 1;
+        if (sp > 120) sp = 120; /* cannot happen for a median split of < 2^60 tris */
+    }
+}
+
+/* ---------------------------------------------------------------- accel build */
+
+static void tri_bounds(const tri_t* t, v3* mn, v3* mx) {
+    mn->x = omin(t->v0.x, omin(t->v1.x, t->v2.x)); mx->x = omax(t->v0.x, omax(t->v1.x, t->v2.x));
+    mn->y = omin(t->v0.y, omin(t->v1.y, t->v2.y)); mx->y = omax(t->v0.y, omax(t->v1.y, t->v2.y));
+    mn->z = omin(t->v0.z, omin(t->v1.z, t->v2.z)); mx->z = omax(t->v0.z, omax(t->v1.z, t->v2.z));
+}
+static int g_axis;
+static int cmp_centroid(const void* a, const void* b) {
+    const tri_t* x = (const tri_t*)a; const tri_t* y = (const tri_t*)b;
+    float cx, cy;
+    if (g_axis == 0) { cx = x->v0.x + x->v1.x + x->v2.x; cy = y->v0.x + y->v1.x + y->v2.x; }
+    else if (g_axis == 1) { cx = x->v0.y + x->v1.y + x->v2.y; cy = y->v0.y + y->v1.y + y->v2.y; }
+    else { cx = x->v0.z + x->v1.z + x->v2.z; cy = y->v0.z + y->v1.z + y->v2.z; }
+    if (cx < cy) return -1; if (cx > cy) return 1;
+    return x->key < y->key ? -1 : (x->key > y->key ? 1 : 0);
+}
+static void build_rec(orc_ctx* c, uint32_t node, uint32_t first, uint32_t count, float pad) {
+    v3 mn = V3(INFINITY, INFINITY, INFINITY), mx = V3(-INFINITY, -INFINITY, -INFINITY);
+    v3 cmn = mn, cmx = mx;
+    for (uint32_t i = 0; i < count; i++) {
+        v3 a, b; tri_bounds(&c->tris[first + i], &a, &b);
+        mn.x = omin(mn.x, a.x); mn.y = omin(mn.y, a.y); mn.z = omin(mn.z, a.z);
+        mx.x = omax(mx.x, b.x); mx.y = omax(mx.y, b.y); mx.z = omax(mx.z, b.z);
+        v3 ce = vadd(a, b);
+        cmn.x = omin(cmn.x, ce.x); cmn.y = omin(cmn.y, ce.y); cmn.z = omin(cmn.z, ce.z);
+        cmx.x = omax(cmx.x, ce.x); cmx.y = omax(cmx.y, ce.y); cmx.z = omax(cmx.z, ce.z);
+    }
+    bnode_t* n = &c->nodes[node];
+    n->bmin = V3(mn.x - pad, mn.y - pad, mn.z - pad); n->bmax = V3(mx.x + pad, mx.y + pad, mx.z + pad);
+    if (count <= 4) { n->left = first; n->count = count; return; }
+    v3 ext = vsub(cmx, cmn);
+    int axis = ext.x >= ext.y && ext.x >= ext.z ? 0 : (ext.y >= ext.z ? 1 : 2);
+    g_axis = axis;
+    qsort(&c->tris[first], count, sizeof(tri_t), cmp_centroid);
+    uint32_t half = count / 2;
+    uint32_t l = c->n_nodes; c->n_nodes += 2;
+    n = &c->nodes[node]; n->left = l; n->count = 0;
+    build_rec(c, l, first, half, pad);
+    build_rec(c, l + 1, first + half, count - half, pad);
+}
+
+int orc_commit(orc_ctx* c, int accel) {
+    free(c->tris); free(c->nodes); c->tris = NULL; c->nodes = NULL; c->n_nodes = 0;
+    uint32_t total = 0;
+    for (int s = 0; s < MAX_GEOMETRIES; s++) total += c->geo[s].n_tri;
+    c->n_tris = total; c->accel = accel;
+    c->tris = (tri_t*)malloc(sizeof(tri_t) * (total ? total : 1));
+    uint32_t k = 0; float maxabs = 1.0f;
+    for (int s = 0; s < MAX_GEOMETRIES; s++) {
+        geo_t* g = &c->geo[s];
+        for (uint32_t i = 0; i < g->n_tri; i++) {
+            tri_t* t = &c->tris[k++];
+            const float* a = g->vtx + 3 * g->idx[3 * i], *b = g->vtx + 3 * g->idx[3 * i + 1], *d = g->vtx + 3 * g->idx[3 * i + 2];
+            t->v0 = V3(a[0], a[1], a[2]); t->v1 = V3(b[0], b[1], b[2]); t->v2 = V3(d[0], d[1], d[2]);
+            t->key = ((uint32_t)s << 28) | i; t->opaque = (g->flags & ORC_GEO_OPAQUE) ? 1u : 0u;
+            for (int j = 0; j < 3; j++) { maxabs = omax(maxabs, fabsf(a[j])); maxabs = omax(maxabs, fabsf(b[j])); maxabs = omax(maxabs, fabsf(d[j])); }
+        }
+    }
+    if (accel && total) {
+        c->nodes = (bnode_t*)malloc(sizeof(bnode_t) * (2 * (size_t)total + 2));
+        c->n_nodes = 1;
+        build_rec(c, 0, 0, total, omax(1e-4f, maxabs * 4.76837158203125e-07f));
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- state */
+
+int orc_connect(orc_ctx* c, uint32_t w, uint32_t h) {
+    free_state(c);
+    c->W = w; c->H = h;
+    size_t px = (size_t)w * h;
+    c->mc_total = c->p.mc_adaptive_buffer_size + c->p.mc_static_buffer_size; /* render_mcpg.cpp:59,88 */
+    c->mc = (mcstate_t*)calloc(c->mc_total, sizeof(mcstate_t));
+    c->lc = (lcvertex_t*)calloc(c->p.lc_buffer_size, sizeof(lcvertex_t));
+    c->upd_count = (uint32_t*)calloc(c->mc_total, 4);
+    c->upd_rec = (uint32_t*)calloc(c->mc_total, 4);
+    size_t segs = px * (size_t)(c->p.spp > 0 ? c->p.spp : 1) * (size_t)(c->p.max_path_length > 1 ? c->p.max_path_length - 1 : 1);
+    c->upd_pool_cap = (uint32_t)(segs < c->mc_total ? segs : c->mc_total);
+    c->upd_pool = (mcupdate_t*)calloc(c->upd_pool_cap ? c->upd_pool_cap : 1, sizeof(mcupdate_t));
+    c->upd_touched = (uint32_t*)calloc(c->upd_pool_cap ? c->upd_pool_cap : 1, 4);
+    c->irradiance = (float*)calloc(px, 16);
+    c->gb_albedo = (uint16_t*)calloc(px, 8); c->gb_irr = (uint16_t*)calloc(px, 8); c->gb_mv = (uint16_t*)calloc(px, 4);
+    c->gbuffer = (gbuf_t*)calloc(px, sizeof(gbuf_t)); c->hits = (chit_t*)calloc(px, sizeof(chit_t));
+    if (!c->mc || !c->lc || !c->upd_count || !c->upd_rec || !c->upd_pool || !c->irradiance || !c->hits) return -1;
+    return 0;
+}
+
+const void* orc_output(orc_ctx* c, int which, size_t* bytes) {
+    size_t px = (size_t)c->W * c->H;
+    switch (which) {
+    case ORC_OUT_IRRADIANCE: if (bytes) *bytes = px * 16; return c->irradiance;
+    case ORC_OUT_GB_ALBEDO: if (bytes) *bytes = px * 8; return c->gb_albedo;
+    case ORC_OUT_GB_IRRADIANCE: if (bytes) *bytes = px * 8; return c->gb_irr;
+    case ORC_OUT_GB_MV: if (bytes) *bytes = px * 4; return c->gb_mv;
+    case ORC_OUT_GBUFFER: if (bytes) *bytes = px * sizeof(gbuf_t); return c->gbuffer;
+    case ORC_OUT_HITS: if (bytes) *bytes = px * sizeof(chit_t); return c->hits;
+    }
+    return NULL;
+}
+void orc_get_counters(orc_ctx* c, orc_counters_t* out, int reset) { if (out) *out = c->ctr; if (reset) memset(&c->ctr, 0, sizeof c->ctr); }
+
+/* ---------------------------------------------------------------- sky + trace_ray */
+
+typedef struct { const orc_ctx* c; orc_counters_t ctr; uint32_t rng; v3 sun_color; } tls_t;
+
+static inline v3 cam_x(const orc_ctx* c) { return V3(c->u.cam_x[0], c->u.cam_x[1], c->u.cam_x[2]); }
+
+/* raytrace.glsl:25-60 */
+static v3 get_sky(const orc_ctx* c, v3 w, v3 sun_color) {
+    v3 sun = V3(c->p.sun_w[0], c->p.sun_w[1], c->p.sun_w[2]);
+    float a = 0.5f * (1.0f + vdot(sun, w));
+    float a2 = a * a;
+    float glow = 0.5f * (a2 * a2) + 5.0f * orc_vmf_pdf(w, sun, 3000.0f);
+    v3 emm = orc_rh3(vscale(sun_color, orc_rh(glow)));
+    const orc_uniform_t* u = &c->u;
+    if ((u->sky_lf_ft & 0xffffu) == 0xffffu) { /* classic two-layer quake sky */
+        float az = fabsf(w.z);
+        float s = 0.5f + w.x / az, t = 0.5f + w.y / az;
+        float tm = u->cl_time * 0.12f;
+        v4 bck = tex_sample(c, u->sky_rt_bk & 0xffffu, s + 0.5f * tm, t + 0.5f * tm);
+        v4 fnt = tex_sample(c, u->sky_rt_bk >> 16, s + tm, t + tm);
+        v3 tex = V3(omix(bck.r, fnt.r, fnt.a), omix(bck.g, fnt.g, fnt.a), omix(bck.b, fnt.b, fnt.a));
+        emm = orc_rh3(V3(10.0f * (orc_exp2(3.5f * orc_rh(tex.x)) - 1.0f), 10.0f * (orc_exp2(3.5f * orc_rh(tex.y)) - 1.0f), 10.0f * (orc_exp2(3.5f * orc_rh(tex.z)) - 1.0f)));
+    } else {
+        float ax = fabsf(w.x), ay = fabsf(w.y), az = fabsf(w.z);
+        int side_i; /* cubemap_side: dominant axis, +x 0, -x 1, +y 2, -y 3, +z 4, -z 5 */
+        if (ax >= ay && ax >= az) side_i = w.x >= 0 ? 0 : 1; else if (ay >= az) side_i = w.y >= 0 ? 2 : 3; else side_i = w.z >= 0 ? 4 : 5;
+        uint32_t side = 0; float s = 0, t = 0;
+        switch (side_i) {
+        case 0: side = u->sky_rt_bk & 0xffffu; s = 0.5f + 0.5f * -w.y / ax; t = 0.5f + 0.5f * -w.z / ax; break;
+        case 1: side = u->sky_lf_ft & 0xffffu; s = 0.5f + 0.5f * w.y / ax; t = 0.5f + 0.5f * -w.z / ax; break;
+        case 2: side = u->sky_rt_bk >> 16; s = 0.5f + 0.5f * w.x / ay; t = 0.5f + 0.5f * -w.z / ay; break;
+        case 3: side = u->sky_lf_ft >> 16; s = 0.5f + 0.5f * -w.x / ay; t = 0.5f + 0.5f * -w.z / ay; break;
+        case 4: side = u->sky_up_dn & 0xffffu; s = 0.5f + 0.5f * -w.y / az; t = 0.5f + 0.5f * w.x / az; break;
+        default: side = u->sky_up_dn >> 16; s = 0.5f + 0.5f * -w.y / az; t = 0.5f + 0.5f * -w.x / az; break;
+        }
+        if (side < MAX_GLTEXTURES) { v4 tx = tex_sample(c, side, s, t); emm = orc_rh3(V3(emm.x + orc_rh(tx.r), emm.y + orc_rh(tx.g), emm.z + orc_rh(tx.b))); }
+    }
+    return emm;
+}
+
+static inline v3 rd3(const float* p, uint32_t i) { return V3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+/* raytrace.glsl:156-311.  throughput / contribution / albedo are float16 in the reference: values
+ * are rounded to half at every store. `hit` carries ray origin (pos) and direction (wi) in. */
+static void trace_ray(tls_t* tl, v3* throughput, v3* contribution, hit_t* hit, v3 sun_color) {
+    const orc_ctx* c = tl->c;
+    rayhit_t rh;
+    closest_hit(c, hit->pos, hit->wi, T_MAX, &rh, &tl->ctr);
+    float tq = rh.key == 0xffffffffu ? T_MAX : rh.t;
+    float tr = orc_rh(orc_transmittance(tq, c->u.cam_x[3], c->p.volume_max_t));
+    *throughput = orc_rh3(vscale(*throughput, tr));
+    hit->roughness = orc_rh(0.6f);
+    const orc_ext_t* e = rh.key == 0xffffffffu ? NULL : ext_of(c, rh.key);
+    uint32_t flags = e ? (uint32_t)(e->texnum_fb_flags >> 12) : 0;
+    if (!e || flags == MAT_FLAGS_SKY) { /* :170-194 */
+        v3 sky = get_sky(c, hit->wi, sun_color);
+        v3 add = orc_rh3(vmul(*throughput, sky));
+        *contribution = e ? orc_rh3(vadd(*contribution, add)) : add;
+        hit->albedo = sky;
+        hit->pos = vadd(hit->pos, vscale(hit->wi, T_MAX)); hit->prev_pos = hit->pos;
+        hit->normal = vneg(hit->wi); hit->enc_geonormal = orc_encode_normal(hit->normal);
+        return;
+    }
+    const geo_t* g = &c->geo[rh.key >> 28]; uint32_t prim = rh.key & 0x0fffffffu;
+    float b0 = 1.0f - rh.u - rh.v, b1 = rh.u, b2 = rh.v;
+    float st0s = orc_h2f(e->st[0]), st0t = orc_h2f(e->st[1]), st1s = orc_h2f(e->st[2]), st1t = orc_h2f(e->st[3]), st2s = orc_h2f(e->st[4]), st2t = orc_h2f(e->st[5]);
+    float s = st0s * b0 + st1s * b1 + st2s * b2, t = st0t * b0 + st1t * b1 + st2t * b2;
+    if (flags > 0 && flags < 5) { /* :198-204 warp (DEFINED: quake turbulence in normalised st) */
+        float ws = s + 0.125f * orc_sin(8.0f * t + c->u.cl_time), wt = t + 0.125f * orc_sin(8.0f * s + c->u.cl_time);
+        s = ws; t = wt;
+        if (flags == MAT_FLAGS_WATER) {
+            float as = 0.02f * orc_sin(20.0f * t + 1.7f * c->u.cl_time), at = 0.02f * orc_sin(20.0f * s + 1.3f * c->u.cl_time);
+            s += as; t += at;
+            hit->roughness = orc_rh(0.4f);
+        }
+    }
+    uint32_t i0 = g->idx[3 * prim], i1 = g->idx[3 * prim + 1], i2 = g->idx[3 * prim + 2];
+    v3 p0 = rd3(g->vtx, i0), p1 = rd3(g->vtx, i1), p2 = rd3(g->vtx, i2);
+    hit->pos = vadd(vadd(vscale(p0, b0), vscale(p1, b1)), vscale(p2, b2));
+    v3 du = vsub(p2, p0), dv = vsub(p1, p0);
+    hit->normal = vnormalize(vcross(du, dv));
+    hit->enc_geonormal = orc_encode_normal(hit->normal);
+    hit->prev_pos = vadd(vadd(vscale(rd3(g->prev_vtx, i0), b0), vscale(rd3(g->prev_vtx, i1), b1)), vscale(rd3(g->prev_vtx, i2), b2));
+    v4 at = tex_sample(c, e->texnum_alpha & 0xfffu, s, t);
+    v3 albedo_tex = orc_rh3(V3(orc_pow(orc_rh(at.r), 1.0f / 1.2f), orc_pow(orc_rh(at.g), 1.0f / 1.2f), orc_pow(orc_rh(at.b), 1.0f / 1.2f)));
+    if (e->n1_brush == 0xffffffffu) { /* :249-274 */
+        uint32_t tn_norm = e->n0_gloss_norm >> 16, tn_gloss = e->n0_gloss_norm & 0xffffu;
+        if (tn_norm > 0 && tn_norm < MAX_GLTEXTURES) {
+            v4 nt = tex_sample(c, tn_norm, s, t);
+            v3 tn = V3((nt.r - 0.5f) * 2.0f, (nt.g - 0.5f) * 2.0f, (nt.b - 0.5f) * 2.0f);
+            float d0x = orc_rh(st2s - st0s), d0y = orc_rh(st2t - st0t), d1x = orc_rh(st1s - st0s), d1y = orc_rh(st1t - st0t);
+            float det = orc_rh(orc_rh(d0x * d1y) - orc_rh(d1x * d0y));
+            if (fabsf(det) > 1e-8f) {
+                v3 du2 = vnormalize(vscale(vsub(vscale(du, d1y), vscale(dv, d0y)), 1.0f / det));
+                dv = vneg(vnormalize(vscale(vadd(vscale(du, -d1x), vscale(dv, d0x)), 1.0f / det)));
+                du = du2;
+            }
+            v3 gn = hit->normal;
+            hit->normal = vnormalize(vadd(vadd(vscale(du, tn.x), vscale(dv, tn.y)), vscale(gn, tn.z)));
+            v3 r = vsub(hit->wi, vscale(hit->normal, 2.0f * vdot(hit->wi, hit->normal)));
+            if (vdot(r, gn) < 0.0f) hit->normal = vnormalize(vadd(vneg(hit->wi), vnormalize(vsub(r, vscale(gn, vdot(gn, r))))));
+        }
+        if (tn_gloss > 0 && tn_gloss < MAX_GLTEXTURES) hit->roughness = orc_rh(tex_sample(c, tn_gloss, s, t).r);
+    } else if (flags == MAT_FLAGS_SOLID) { /* :275-278 */
+        uint32_t a = e->n0_gloss_norm, b = e->n1_brush;
+        hit->albedo = orc_rh3(V3(orc_rh((float)(a & 0xff)) / 255.0f, orc_rh((float)((a >> 8) & 0xff)) / 255.0f, orc_rh((float)((a >> 16) & 0xff)) / 255.0f));
+        v3 em = orc_ldr_to_hdr(orc_rh3(V3(orc_rh((float)(b & 0xff)) / 255.0f, orc_rh((float)((b >> 8) & 0xff)) / 255.0f, orc_rh((float)((b >> 16) & 0xff)) / 255.0f)));
+        *contribution = orc_rh3(vadd(*contribution, orc_rh3(vmul(*throughput, em))));
+        return;
+    }
+    if (flags == MAT_FLAGS_WATERFALL) { /* :288-310 */
+        hit->albedo = albedo_tex;
+        *contribution = orc_rh3(vadd(*contribution, orc_rh3(vmul(*throughput, hit->albedo))));
+    } else if (flags == MAT_FLAGS_SPRITE || flags == MAT_FLAGS_TELE) {
+        hit->albedo = orc_ldr_to_hdr(albedo_tex);
+        *contribution = orc_rh3(vadd(*contribution, orc_rh3(vmul(*throughput, hit->albedo))));
+    } else {
+        uint32_t fb = e->texnum_fb_flags & 0xfffu;
+        hit->albedo = albedo_tex;
+        if (fb > 0 && fb < MAX_GLTEXTURES) {
+            v4 ft = tex_sample(c, fb, s, t);
+            v3 em = orc_ldr_to_hdr(orc_rh3(V3(ft.r, ft.g, ft.b)));
+            if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {
+                *contribution = orc_rh3(vadd(*contribution, orc_rh3(vmul(*throughput, em))));
+                hit->albedo = em;
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- g-buffer pass */
+
+static void compress_hit(const hit_t* h, chit_t* o) { /* hit.glsl.h:34-43 */
+    o->pos[0] = h->pos.x; o->pos[1] = h->pos.y; o->pos[2] = h->pos.z;
+    o->mv[0] = orc_f2h(h->pos.x - h->prev_pos.x); o->mv[1] = orc_f2h(h->pos.y - h->prev_pos.y); o->mv[2] = orc_f2h(h->pos.z - h->prev_pos.z);
+    o->_pad = 0;
+    o->wi = orc_encode_normal(h->wi); o->normal = orc_encode_normal(h->normal); o->enc_geonormal = h->enc_geonormal;
+    o->albedo[0] = orc_f2h(h->albedo.x); o->albedo[1] = orc_f2h(h->albedo.y); o->albedo[2] = orc_f2h(h->albedo.z);
+    o->roughness = orc_f2h(h->roughness);
+}
+static void decompress_hit(const chit_t* c, hit_t* h) { /* hit.glsl.h:45-53 */
+    h->pos = V3(c->pos[0], c->pos[1], c->pos[2]);
+    h->prev_pos = V3(c->pos[0] - orc_h2f(c->mv[0]), c->pos[1] - orc_h2f(c->mv[1]), c->pos[2] - orc_h2f(c->mv[2]));
+    h->wi = orc_decode_normal(c->wi); h->normal = orc_decode_normal(c->normal); h->enc_geonormal = c->enc_geonormal;
+    h->albedo = V3(orc_h2f(c->albedo[0]), orc_h2f(c->albedo[1]), orc_h2f(c->albedo[2]));
+    h->roughness = orc_h2f(c->roughness);
+}
+
+/* gbuffer.comp:75-131 (mip-mapped first-hit texturing is not restated: LOD 0 is used, i.e.
+ * "enable albedo mipmap"/"enable emission mipmap" = false) */
+static void gbuffer_pixel(tls_t* tl, uint32_t px, uint32_t py) {
+    orc_ctx* c = (orc_ctx*)tl->c;
+    const orc_uniform_t* u = &c->u;
+    size_t idx = (size_t)py * c->W + px;
+    float W = (float)c->W, H = (float)c->H, tan_half = c->p.fov_tan_alpha_half;
+    v3 up = V3(u->cam_u[0], u->cam_u[1], u->cam_u[2]), fwd = V3(u->cam_w[0], u->cam_w[1], u->cam_w[2]);
+    v3 r_x = orc_camera_ray_dir((float)px + 1.0f, (float)py, W, H, up, fwd, tan_half);
+    v3 r_y = orc_camera_ray_dir((float)px, (float)py + 1.0f, W, H, up, fwd, tan_half);
+    hit_t h; memset(&h, 0, sizeof h);
+    h.wi = orc_camera_ray_dir((float)px, (float)py, W, H, up, fwd, tan_half);
+    h.pos = cam_x(c);
+    v3 incident = V3(0, 0, 0), thr = V3(1, 1, 1);
+    v3 sun = c->p.gbuffer_hide_sun ? V3(0, 0, 0) : V3(c->p.sun_color[0], c->p.sun_color[1], c->p.sun_color[2]);
+    trace_ray(tl, &thr, &incident, &h, sun);
+    uint16_t* oi = c->gb_irr + 4 * idx;
+    oi[0] = orc_f2h(incident.x); oi[1] = orc_f2h(incident.y); oi[2] = orc_f2h(incident.z); oi[3] = orc_f2h(1.0f);
+    float keep = (incident.x >= 1e-5f || incident.y >= 1e-5f || incident.z >= 1e-5f) ? 0.0f : 1.0f; /* :107 */
+    h.albedo = orc_rh3(vmul(orc_rh3(vscale(h.albedo, keep)), thr));
+    uint16_t* oa = c->gb_albedo + 4 * idx;
+    oa[0] = orc_f2h(h.albedo.x); oa[1] = orc_f2h(h.albedo.y); oa[2] = orc_f2h(h.albedo.z); oa[3] = orc_f2h(1.0f);
+    { /* :111-115 */
+        v3 old_dir = vsub(h.prev_pos, V3(u->prev_cam_x[0], u->prev_cam_x[1], u->prev_cam_x[2]));
+        float opx, opy;
+        orc_camera_pixel(old_dir, W, H, V3(u->prev_cam_u[0], u->prev_cam_u[1], u->prev_cam_u[2]), V3(u->prev_cam_w[0], u->prev_cam_w[1], u->prev_cam_w[2]), tan_half, &opx, &opy);
+        c->gb_mv[2 * idx] = orc_f2h(opx - (float)px); c->gb_mv[2 * idx + 1] = orc_f2h(opy - (float)py);
+    }
+    compress_hit(&h, &c->hits[idx]);
+    { /* :123-130 */
+        v3 gn = orc_decode_normal(h.enc_geonormal);
+        v3 cp = cam_x(c);
+        float lz = vlen(vsub(cp, h.pos));
+        float num = vdot(gn, vsub(h.pos, cp));
+        gbuf_t* gb = &c->gbuffer[idx];
+        gb->enc_normal = orc_encode_normal(h.normal); gb->linear_z = lz;
+        gb->grad_z[0] = orc_f2h(num / vdot(gn, vsub(r_x, h.wi)) - lz); gb->grad_z[1] = orc_f2h(num / vdot(gn, vsub(r_y, h.wi)) - lz);
+        gb->vel_z = vlen(vsub(V3(u->prev_cam_x[0], u->prev_cam_x[1], u->prev_cam_x[2]), h.prev_pos)) - lz;
+    }
+}
+
+/* ---------------------------------------------------------------- grids */
+
+static inline float X(tls_t* tl) { return orc_xorshift(&tl->rng); }
+
+static uint32_t grid_level(int type, float steps, float tan_half, float minw, float power, v3 cam, v3 pos) {
+    float w = 2.0f * tan_half * vlen(vsub(cam, pos));
+    float lv;
+    if (type == 0) lv = steps * orc_log(omax(w, minw) / minw) / orc_log(power); /* mc.glsl:65, light_cache.glsl:16 */
+    else lv = steps * orc_pow(omax(w - minw, 0.0f), 1.0f / power);               /* mc.glsl:67, light_cache.glsl:18 */
+    return (uint32_t)floorf(lv + 0.5f);
+}
+static float grid_width(int type, float steps, float minw, float power, uint32_t level) {
+    if (type == 0) return minw * orc_pow(power, (float)level / steps); /* mc.glsl:73 */
+    return orc_pow((float)level / steps, power) + minw;                /* mc.glsl:75 */
+}
+
+/* mc.glsl:83-88 */
+static void mc_adaptive_buffer_index(tls_t* tl, v3 pos, v3 normal, uint32_t* index, uint16_t* hash) {
+    const orc_params_t* p = &tl->c->p;
+    uint32_t level = grid_level(p->adaptive_grid_type, p->mc_adaptive_grid_steps_per_unit_size, p->mc_adaptive_grid_tan_alpha_half, p->mc_adaptive_grid_min_width, p->mc_adaptive_grid_power, cam_x(tl->c), pos);
+    float xi = X(tl);
+    level += (uint32_t)(-orc_log2(1.0f - xi)); /* mc.glsl:70 */
+    float width = grid_width(p->adaptive_grid_type, p->mc_adaptive_grid_steps_per_unit_size, p->mc_adaptive_grid_min_width, p->mc_adaptive_grid_power, level);
+    i3 g = orc_grid_idx_interpolate(pos, width, X(tl));
+    *index = orc_hash_grid_normal_level(g, normal, level, p->mc_adaptive_buffer_size);
+    *hash = (uint16_t)orc_hash2_grid_level(g, level);
+}
+/* mc.glsl:117-121 */
+static void mc_static_buffer_index(tls_t* tl, v3 pos, uint32_t* index, uint16_t* hash) {
+    const orc_params_t* p = &tl->c->p;
+    i3 g = orc_grid_idx_interpolate(pos, p->mc_static_grid_width, X(tl));
+    *index = orc_hash_grid(g, p->mc_static_buffer_size) + p->mc_adaptive_buffer_size;
+    *hash = (uint16_t)orc_hash2_grid(g);
+}
+
+static inline v3 mc_state_pos(const mcstate_t* s) { return s->sum_w > 0.0f ? vscale(s->w_tgt, 1.0f / s->sum_w) : s->w_tgt; } /* mc.glsl:22 */
+static inline v3 mc_state_dir(const mcstate_t* s, v3 pos) { return vnormalize(vsub(mc_state_pos(s), pos)); }                 /* mc.glsl:20 */
+static inline float mc_state_mean_cos(const orc_params_t* p, const mcstate_t* s, v3 pos) {                                    /* mc.glsl:24-26 */
+    v3 d = vsub(pos, mc_state_pos(s));
+    float prior = omax(0.0001f, p->dir_guide_prior / vdot(d, d));
+    uint32_t nn = (uint32_t)s->N * (uint32_t)s->N;
+    if (p->quirk_n16_wrap) nn &= 0xffffu;
+    float n2 = (float)nn;
+    return (n2 * oclamp(s->w_cos / s->sum_w, 0.0f, 0.9999999f)) / (n2 + prior);
+}
+static inline float mc_state_kappa(const orc_params_t* p, const mcstate_t* s, v3 pos) { /* mc.glsl:43-46 */
+    float r = mc_state_mean_cos(p, s, pos);
+    return (3.0f * r - r * r * r) / (1.0f - r * r);
+}
+static int mc_light_missing(const orc_params_t* p, const mcstate_t* s, float mc_f, v3 wo, v3 pos) { /* mc.glsl:28-41 */
+    if (mc_f > 1e-3f * s->sum_w) return 0;
+    float co = vdot(wo, mc_state_dir(s, pos));
+    if (co < 0.9f + 0.1f * mc_state_mean_cos(p, s, pos)) return 0;
+    return 1;
+}
+static inline mcstate_t mc_state_new(tls_t* tl) { /* mc.glsl:17 */
+    mcstate_t s; memset(&s, 0, sizeof s);
+    s.id = (uint32_t)(X(tl) * 4294967296.0f);
+    return s;
+}
+static inline v3 h3(const uint16_t* h) { return V3(orc_h2f(h[0]), orc_h2f(h[1]), orc_h2f(h[2])); }
+static void mc_finalize_load(const orc_ctx* c, mcstate_t* s, uint16_t hash, int is_static, v3 pos, v3 normal) { /* mc.glsl:90-96,130-135 */
+    int bad = s->sum_w < 0.0f || hash != s->hash;
+    if (!bad && is_static) bad = !(vdot(normal, mc_state_dir(s, pos)) > 0.0f);
+    if (bad) s->sum_w = 0.0f;
+    float k = s->sum_w * (c->u.cl_time - s->T);
+    s->w_tgt = vadd(s->w_tgt, vscale(h3(s->mv), k));
+}
+
+/* mc.glsl:159-184, 207-222 */
+static void mc_state_add_sample(tls_t* tl, const mcstate_t* st, v3 pos, float w, v3 target, v3 target_mv, v3 normal, uint32_t mc_buffer_index) {
+    orc_ctx* c = (orc_ctx*)tl->c;
+    uint32_t index = mc_buffer_index;
+    if (index == 0xffffffffu) { uint16_t h; mc_adaptive_buffer_index(tl, pos, normal, &index, &h); }
+    uint32_t old = __atomic_fetch_add(&c->upd_count[index], 1u, __ATOMIC_RELAXED);
+    if (old >= MAX_UPDATES) { __atomic_fetch_sub(&c->upd_count[index], 1u, __ATOMIC_RELAXED); tl->ctr.mc_updates_dropped++; return; }
+    uint32_t rec;
+    if (old == 0) {
+        rec = __atomic_fetch_add(&c->upd_pool_used, 1u, __ATOMIC_RELAXED);
+        if (rec >= c->upd_pool_cap) { __atomic_fetch_sub(&c->upd_count[index], 1u, __ATOMIC_RELAXED); return; }
+        c->upd_touched[rec] = index;
+        c->upd_pool[rec].T = c->u.cl_time;
+        __atomic_store_n(&c->upd_rec[index], rec + 1, __ATOMIC_RELEASE);
+    } else {
+        uint32_t r1;
+        while ((r1 = __atomic_load_n(&c->upd_rec[index], __ATOMIC_ACQUIRE)) == 0) { /* racy mode only */ }
+        rec = r1 - 1;
+    }
+    mcupdate_t* up = &c->upd_pool[rec];
+    up->normals[old] = normal;
+    up->mv[old][0] = orc_f2h(target_mv.x); up->mv[old][1] = orc_f2h(target_mv.y); up->mv[old][2] = orc_f2h(target_mv.z);
+    up->ids[old] = st->id; up->targets[old] = target; up->weights[old] = w; up->positions[old] = pos;
+    tl->ctr.mc_updates_accepted++;
+}
+
+/* ---------------------------------------------------------------- light cache */
+
+static void lc_address(tls_t* tl, uint32_t level, v3 pos, v3 normal, uint32_t* idx, uint32_t* chk) {
+    const orc_params_t* p = &tl->c->p;
+    float width = grid_width(p->lc_grid_type, p->lc_grid_steps_per_unit_size, p->lc_grid_min_width, p->lc_grid_power, level);
+    i3 g = orc_grid_idx_interpolate(pos, width, X(tl)); /* light_cache.glsl:29 */
+    *idx = orc_hash_grid_normal_level(g, normal, level, p->lc_buffer_size);
+    *chk = orc_hash2_grid_level(g, level);
+}
+static inline int h_bad(uint16_t h) { return (h & 0x7c00u) == 0x7c00u; } /* inf or nan */
+/* light_cache.glsl:31-45 */
+static void light_cache_get_level(tls_t* tl, v3* irr, uint16_t* N, uint32_t level, v3 pos, v3 normal) {
+    uint32_t idx, chk;
+    lc_address(tl, level, pos, normal, &idx, &chk);
+    const lcvertex_t* v = &tl->c->lc[idx];
+    tl->ctr.lc_touches++;
+    if (v->hash == chk && !h_bad(v->irr[0]) && !h_bad(v->irr[1]) && !h_bad(v->irr[2])) { *irr = h3(v->irr); *N = v->N; }
+    else { *irr = V3(0, 0, 0); *N = 0; }
+}
+static inline uint32_t lc_level(const orc_ctx* c, v3 pos) {
+    const orc_params_t* p = &c->p;
+    return grid_level(p->lc_grid_type, p->lc_grid_steps_per_unit_size, p->lc_grid_tan_alpha_half, p->lc_grid_min_width, p->lc_grid_power, cam_x(c), pos);
+}
+/* light_cache.glsl:47-52 */
+static v3 light_cache_get(tls_t* tl, v3 pos, v3 normal) {
+    v3 irr; uint16_t N;
+    light_cache_get_level(tl, &irr, &N, lc_level(tl->c, pos), pos, normal);
+    return irr;
+}
+/* light_cache.glsl:54-84 */
+static void light_cache_update(tls_t* tl, v3 pos, v3 normal, v3 irr) {
+    orc_ctx* c = (orc_ctx*)tl->c;
+    uint32_t level = lc_level(c, pos), idx, chk;
+    lc_address(tl, level, pos, normal, &idx, &chk);
+    lcvertex_t* cell = &c->lc[idx];
+    tl->ctr.lc_touches++;
+    uint32_t old = __atomic_exchange_n(&cell->lock, c->u.frame, __ATOMIC_ACQ_REL);
+    if (old == c->u.frame) { __atomic_fetch_add(&cell->cancel, 1u, __ATOMIC_RELAXED); return; }
+    lcvertex_t v = *cell;
+    if (v.hash != chk || h_bad(v.irr[0]) || h_bad(v.irr[1]) || h_bad(v.irr[2])) {
+        v3 ci; uint16_t cn;
+        light_cache_get_level(tl, &ci, &cn, level + 1, pos, normal);
+        v.irr[0] = orc_f2h(ci.x); v.irr[1] = orc_f2h(ci.y); v.irr[2] = orc_f2h(ci.z); v.N = cn;
+        v.hash = chk;
+    }
+    v.N = (uint16_t)(v.N + 1 < LIGHT_CACHE_MAX_N ? v.N + 1 : LIGHT_CACHE_MAX_N);
+    float a = omax(1.0f / (float)v.N, LIGHT_CACHE_MIN_ALPHA);
+    v3 cur = h3(v.irr);
+    v.irr[0] = orc_f2h(omix(cur.x, irr.x, a)); v.irr[1] = orc_f2h(omix(cur.y, irr.y, a)); v.irr[2] = orc_f2h(omix(cur.z, irr.z, a));
+    cell->hash = v.hash; cell->irr[0] = v.irr[0]; cell->irr[1] = v.irr[1]; cell->irr[2] = v.irr[2]; cell->N = v.N;
+    __atomic_fetch_add(&cell->ok, 1u, __ATOMIC_RELAXED);
+    __atomic_store_n(&cell->lock, 0u, __ATOMIC_RELEASE);
+}
+
+/* ---------------------------------------------------------------- surface estimator */
+
+#define MAX_MC_SAMPLES 32
+static inline int finite3(v3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+
+/* mcpg.comp:39-210 */
+static void mcpg_pixel(tls_t* tl, uint32_t px, uint32_t py) {
+    orc_ctx* c = (orc_ctx*)tl->c;
+    const orc_params_t* p = &c->p;
+    size_t idx = (size_t)py * c->W + px;
+    tl->rng = orc_pcg4d16(px, py, c->u.frame, p->seed); /* :40 */
+    float second_moment = 0.0f; v3 irr = V3(0, 0, 0);
+    const chit_t* fh = &c->hits[idx];
+    v3 sun = V3(p->sun_color[0], p->sun_color[1], p->sun_color[2]);
+    int refmode = p->reference_mode || p->surf_bsdf_p == 1.0f; /* render_mcpg.cpp:139-140 */
+    int K = p->mc_samples < MAX_MC_SAMPLES ? p->mc_samples : MAX_MC_SAMPLES;
+    if (orc_h2f(fh->albedo[0]) >= 1e-7f || orc_h2f(fh->albedo[1]) >= 1e-7f || orc_h2f(fh->albedo[2]) >= 1e-7f) /* :44 */
+    for (int s = 0; s < p->spp; s++) {
+        hit_t cur; decompress_hit(fh, &cur);
+        v3 thr = V3(1, 1, 1), f = V3(0, 0, 0); float pp = 1.0f;
+        for (int segment = 1; segment < p->max_path_length; segment++) {
+            v3 wo; float wodotn, wo_p = 0.0f;
+            float alpha = orc_roughness_to_alpha(cur.roughness);
+            mcstate_t mc_state; memset(&mc_state, 0, sizeof mc_state);
+            uint32_t mc_buffer_index = 0xffffffffu; float score_sum = 0.0f;
+            tl->ctr.segments++;
+            if (refmode) { /* :59-64 */
+                float x0 = X(tl), x1 = X(tl), x2 = X(tl);
+                wo = orc_bsdf_sample(cur.wi, cur.normal, alpha, x0, x1, x2);
+                wodotn = vdot(wo, cur.normal);
+                if (wodotn <= 1e-3f || vdot(wo, orc_decode_normal(cur.enc_geonormal)) <= 1e-3f) break;
+                wo_p = orc_bsdf_pdf(cur.wi, wo, cur.normal, alpha);
+            } else { /* :67-137 */
+                float scores[MAX_MC_SAMPLES] = {0}; v3 vdir[MAX_MC_SAMPLES]; float vk[MAX_MC_SAMPLES] = {0};
+                memset(vdir, 0, sizeof vdir);
+                tl->ctr.guided_segments++;
+                for (int i = 0; i < K; i++) {
+                    int adaptive = X(tl) < p->mc_samples_adaptive_prob;
+                    uint32_t bi; uint16_t hash;
+                    v3 lp = s == 0 ? cur.prev_pos : cur.pos;
+                    if (adaptive) mc_adaptive_buffer_index(tl, lp, cur.normal, &bi, &hash);
+                    else mc_static_buffer_index(tl, lp, &bi, &hash);
+                    mcstate_t st = c->mc[bi];
+                    tl->ctr.mc_state_reads++;
+                    mc_finalize_load(c, &st, hash, !adaptive, cur.pos, cur.normal);
+                    score_sum += st.sum_w;
+                    v3 d = mc_state_dir(&st, cur.pos); float kk = mc_state_kappa(p, &st, cur.pos);
+                    if (X(tl) < st.sum_w / score_sum) { /* NaN compares false */
+                        mc_state = st; mc_buffer_index = bi;
+                        vdir[i] = vdir[0]; vk[i] = vk[0]; scores[i] = scores[0];
+                        scores[0] = st.sum_w; vdir[0] = d; vk[0] = kk;
+                    } else { scores[i] = st.sum_w; vdir[i] = d; vk[i] = kk; }
+                }
+                if (score_sum == 0.0f || X(tl) < p->surf_bsdf_p) { /* :113-117 */
+                    float x0 = X(tl), x1 = X(tl), x2 = X(tl);
+                    wo = orc_bsdf_sample(cur.wi, cur.normal, alpha, x0, x1, x2);
+                    mc_state = mc_state_new(tl);
+                    mc_buffer_index = 0xffffffffu;
+                } else {
+                    float x0 = X(tl), x1 = X(tl);
+                    wo = orc_vmf_sample(vdir[0], vk[0], x0, x1);
+                }
+                wodotn = vdot(wo, cur.normal);
+                if (wodotn <= 1e-3f || vdot(wo, orc_decode_normal(cur.enc_geonormal)) <= 1e-3f) break; /* :124 */
+                if (score_sum > 0.0f) {
+                    for (int i = 0; i < K; i++) wo_p += scores[i] * orc_vmf_pdf(wo, vdir[i], vk[i]);
+                    wo_p /= score_sum;
+                }
+                wo_p = (score_sum > 0.0f ? p->surf_bsdf_p : 1.0f) * orc_bsdf_pdf(cur.wi, wo, cur.normal, alpha) + (1.0f - p->surf_bsdf_p) * wo_p; /* :135 */
+            }
+            hit_t next; memset(&next, 0, sizeof next);
+            next.wi = wo;
+            next.pos = vsub(cur.pos, vscale(cur.wi, 1e-3f)); /* :144 */
+            v3 incident = V3(0, 0, 0), throughput = V3(1, 1, 1);
+            trace_ray(tl, &throughput, &incident, &next, sun);
+            v3 lc_incident; /* :149 */
+            if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (p->use_light_cache_tail == 0 && p->max_path_length == 2)) lc_incident = incident;
+            else lc_incident = orc_rh3(vmul(throughput, light_cache_get(tl, next.pos, next.normal)));
+            float bsdf = orc_bsdf_times_wodotn(cur.wi, wo, cur.normal, alpha, 0.02f); /* :153 */
+            thr = vscale(thr, bsdf);
+            if (p->use_light_cache_tail) f = vmul(thr, segment < p->max_path_length - 1 ? incident : lc_incident);
+            else f = vmul(thr, incident);
+            pp *= wo_p;
+            thr = vmul(thr, throughput);
+            if (!refmode) { /* :165-181 */
+                float mc_f = orc_luminance(vscale(vscale(lc_incident, bsdf), 1.0f / wo_p));
+                if (isfinite(mc_f)) {
+                    float den = p->quirk_lc_max_wo_p ? omax(wo_p, 10.0f) : omax(wo_p, 1e-6f);
+                    light_cache_update(tl, cur.pos, cur.normal, vscale(vscale(vmul(lc_incident, vscale(cur.albedo, ORC_INV_PI)), wodotn), 1.0f / den));
+                    if (X(tl) * score_sum < mc_f * (float)p->mc_samples) {
+                        v3 mv = orc_rh3(vscale(vsub(next.pos, next.prev_pos), 1.0f / c->u.cam_w[3]));
+                        mc_state_add_sample(tl, &mc_state, cur.pos, mc_f, next.pos, mv, cur.normal, mc_buffer_index);
+                    } else if (p->mc_fast_recovery && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur.pos)) {
+                        c->mc[mc_buffer_index].sum_w = 0.0f; /* :177 */
+                    }
+                }
+            }
+            thr = vmul(thr, next.albedo); /* :184 */
+            cur = next;
+            if ((thr.x < 1e-7f && thr.y < 1e-7f && thr.z < 1e-7f) || (f.x > 1e-7f || f.y > 1e-7f || f.z > 1e-7f)) break;
+        }
+        v3 contrib = vscale(f, 1.0f / pp); /* :193 */
+        if (finite3(contrib)) { irr = vadd(irr, contrib); float l = orc_luminance(contrib); second_moment += l * l; }
+    }
+    if (p->spp > 0) { float inv = 1.0f / (float)p->spp; irr = vscale(irr, inv); second_moment *= inv; }
+    float* o = c->irradiance + 4 * idx;
+    o[0] = irr.x; o[1] = irr.y; o[2] = irr.z; o[3] = second_moment;
+}
+
+/* ---------------------------------------------------------------- update application */
+
+/* compute_updates.comp:41-54 */
+static void mc_update(mcstate_t* s, v3 pos, float w, v3 target, const uint16_t* mv) {
+    s->N = (uint16_t)(s->N + 1 < ML_MAX_N ? s->N + 1 : ML_MAX_N);
+    float alpha = omax(1.0f / (float)s->N, ML_MIN_ALPHA);
+    s->sum_w = omix(s->sum_w, w, alpha);
+    s->w_tgt = V3(omix(s->w_tgt.x, w * target.x, alpha), omix(s->w_tgt.y, w * target.y, alpha), omix(s->w_tgt.z, w * target.z, alpha));
+    /* :51 reads the state after :49-50 assigned sum_w and w_tgt */
+    float co = omax(0.0f, vdot(vnormalize(vsub(target, pos)), mc_state_dir(s, pos)));
+    s->w_cos = omin(omix(s->w_cos, w * co, alpha), s->sum_w);
+    s->mv[0] = mv[0]; s->mv[1] = mv[1]; s->mv[2] = mv[2];
+}
+
+/* compute_updates.comp:56-124 for one slot */
+static void apply_slot(tls_t* tl, uint32_t slot) {
+    orc_ctx* c = (orc_ctx*)tl->c;
+    uint32_t count = c->upd_count[slot];
+    if (!count) return;
+    if (count > MAX_UPDATES) count = MAX_UPDATES; /* SURVEY D.2 */
+    const mcupdate_t* up = &c->upd_pool[c->upd_rec[slot] - 1];
+    tl->rng = orc_pcg4d16(slot, 0, c->u.frame, c->p.seed); /* :62 */
+    mcstate_t mc_state = c->mc[slot];
+    float sum = 0.0f; v3 pos = V3(0, 0, 0), normal = V3(0, 0, 0);
+    mcstate_t new_state; memset(&new_state, 0, sizeof new_state); int picked = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        mcstate_t st = mc_state;
+        if (mc_state.id != up->ids[i]) st = mc_state_new(tl);
+        mc_update(&st, up->positions[i], up->weights[i], up->targets[i], up->mv[i]);
+        if (mc_state.id == st.id) mc_state = st;
+        sum += st.sum_w;
+        if (X(tl) < st.sum_w / sum) { new_state = st; pos = up->positions[i]; normal = up->normals[i]; picked = 1; }
+    }
+    new_state.T = up->T;
+    if (picked) for (uint32_t i = 0; i < count; i++) {
+        { uint32_t bi; uint16_t hash; mc_static_buffer_index(tl, pos, &bi, &hash);
+          new_state.hash = hash; mcstate_t old = c->mc[bi];
+          if (old.id == new_state.id || X(tl) < new_state.sum_w / (new_state.sum_w + old.sum_w)) c->mc[bi] = new_state; }
+        { uint32_t bi; uint16_t hash; mc_adaptive_buffer_index(tl, pos, normal, &bi, &hash);
+          new_state.hash = hash; mcstate_t old = c->mc[bi];
+          if (old.id == new_state.id || X(tl) < new_state.sum_w / (new_state.sum_w + old.sum_w)) c->mc[bi] = new_state; }
+    }
+    c->upd_count[slot] = 0; c->upd_rec[slot] = 0;
+}
+static int cmp_u32(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
+
+/* ---------------------------------------------------------------- frame driver */
+
+typedef struct { orc_ctx* c; int tid, nthreads, pass; orc_counters_t ctr; } job_t;
+static void* worker(void* arg) {
+    job_t* j = (job_t*)arg; orc_ctx* c = j->c;
+    tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
+    for (uint32_t y = (uint32_t)j->tid; y < c->H; y += (uint32_t)j->nthreads)
+        for (uint32_t x = 0; x < c->W; x++) { if (j->pass == 0) gbuffer_pixel(&tl, x, y); else mcpg_pixel(&tl, x, y); }
+    j->ctr = tl.ctr;
+    return NULL;
+}
+static void acc_ctr(orc_counters_t* a, const orc_counters_t* b) {
+    a->rays += b->rays; a->nodes += b->nodes; a->tris += b->tris; a->segments += b->segments; a->guided_segments += b->guided_segments;
+    a->lc_touches += b->lc_touches; a->mc_updates_accepted += b->mc_updates_accepted; a->mc_updates_dropped += b->mc_updates_dropped; a->mc_state_reads += b->mc_state_reads;
+}
+static void run_pass(orc_ctx* c, int pass, int threads) {
+    if (threads < 1) threads = 1; if (threads > 256) threads = 256;
+    job_t jobs[256]; pthread_t th[256];
+    for (int i = 0; i < threads; i++) { jobs[i].c = c; jobs[i].tid = i; jobs[i].nthreads = threads; jobs[i].pass = pass; memset(&jobs[i].ctr, 0, sizeof(orc_counters_t)); }
+    if (threads == 1) worker(&jobs[0]);
+    else { for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, &jobs[i]); for (int i = 0; i < threads; i++) pthread_join(th[i], NULL); }
+    for (int i = 0; i < threads; i++) acc_ctr(&c->ctr, &jobs[i].ctr);
+}
+
+int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
+    if (!c->irradiance) return -1;
+    c->u = *u;
+    size_t px = (size_t)c->W * c->H;
+    if (!render) { /* clear.comp:15-23, gbuffer.comp:83-90 */
+        memset(c->irradiance, 0, px * 16); memset(c->gb_albedo, 0, px * 8); memset(c->gb_irr, 0, px * 8); memset(c->gb_mv, 0, px * 4);
+        memset(c->gbuffer, 0, px * sizeof(gbuf_t));
+        return 0;
+    }
+    run_pass(c, 0, threads);
+    run_pass(c, 1, threads);
+    /* update pass, render_mcpg.cpp:270-277: every touched slot, ascending slot order */
+    uint32_t n = c->upd_pool_used < c->upd_pool_cap ? c->upd_pool_used : c->upd_pool_cap;
+    qsort(c->upd_touched, n, 4, cmp_u32);
+    tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
+    for (uint32_t i = 0; i < n; i++) apply_slot(&tl, c->upd_touched[i]);
+    acc_ctr(&c->ctr, &tl.ctr);
+    c->upd_pool_used = 0;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- ray queries + KATs */
+
+int orc_trace_rays(orc_ctx* c, const float* org, const float* dir, uint32_t n, uint32_t* out_prim, float* out_t, float* out_uv) {
+    orc_counters_t ctr; memset(&ctr, 0, sizeof ctr);
+    for (uint32_t i = 0; i < n; i++) {
+        rayhit_t h;
+        closest_hit(c, V3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), V3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), T_MAX, &h, &ctr);
+        out_prim[i] = h.key; out_t[i] = h.key == 0xffffffffu ? T_MAX : h.t;
+        if (out_uv) { out_uv[2 * i] = h.u; out_uv[2 * i + 1] = h.v; }
+    }
+    acc_ctr(&c->ctr, &ctr);
+    return 0;
+}
+
+static const int k_arity[ORC_OP_COUNT][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}};
+int orc_op_arity(int op, int* n_in, int* n_out) {
+    if (op < 0 || op >= ORC_OP_COUNT) return -1;
+    *n_in = k_arity[op][0]; *n_out = k_arity[op][1];
+    return 0;
+}
+int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n) {
+    int ni, no;
+    if (orc_op_arity(op, &ni, &no)) return -1;
+    for (uint32_t k = 0; k < n; k++) {
+        const float* a = in + (size_t)k * ni; float* o = out + (size_t)k * no;
+        switch (op) {
+        case ORC_OP_EXP2: o[0] = orc_exp2(a[0]); break;
+        case ORC_OP_LOG2: o[0] = orc_log2(a[0]); break;
+        case ORC_OP_SINCOS2PI: orc_sincos2pi(a[0], &o[0], &o[1]); break;
+        case ORC_OP_POW: o[0] = orc_pow(a[0], a[1]); break;
+        case ORC_OP_F2H2F: o[0] = orc_rh(a[0]); break;
+        case ORC_OP_ENC_DEC_NORMAL: { uint32_t e = orc_encode_normal(V3(a[0], a[1], a[2])); v3 d = orc_decode_normal(e); o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = u2f(e); break; }
+        case ORC_OP_BSDF_SAMPLE: {
+            v3 wi = V3(a[0], a[1], a[2]), nn = V3(a[3], a[4], a[5]); float al = orc_roughness_to_alpha(a[6]);
+            v3 wo = orc_bsdf_sample(wi, nn, al, a[7], a[8], a[9]);
+            o[0] = wo.x; o[1] = wo.y; o[2] = wo.z; o[3] = orc_bsdf_pdf(wi, wo, nn, al); o[4] = orc_bsdf_times_wodotn(wi, wo, nn, al, 0.02f); break; }
+        case ORC_OP_VMF_SAMPLE: { v3 mu = V3(a[0], a[1], a[2]); v3 w = orc_vmf_sample(mu, a[3], a[4], a[5]); o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = orc_vmf_pdf(w, mu, a[3]); break; }
+        case ORC_OP_XORSHIFT: { uint32_t s = f2u(a[0]); for (int i = 0; i < 4; i++) o[i] = orc_xorshift(&s); break; }
+        case ORC_OP_PCG4D16: o[0] = u2f(orc_pcg4d16(f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3]))); break;
+        case ORC_OP_SKY: { orc_uniform_t save = c->u; c->u.sky_lf_ft = 0xfffe; c->u.sky_rt_bk = 0xffffffffu; c->u.sky_up_dn = 0xffffffffu;
+            v3 s = get_sky(c, V3(a[0], a[1], a[2]), V3(c->p.sun_color[0], c->p.sun_color[1], c->p.sun_color[2])); c->u = save; o[0] = s.x; o[1] = s.y; o[2] = s.z; break; }
+        case ORC_OP_HASHGRID: { i3 g = orc_grid_idx_interpolate(V3(a[0], a[1], a[2]), a[7], 0.5f); uint32_t lv = (uint32_t)a[6];
+            o[0] = u2f(orc_hash_grid_normal_level(g, V3(a[3], a[4], a[5]), lv, f2u(a[8]))); o[1] = u2f(orc_hash2_grid_level(g, lv)); break; }
+        case ORC_OP_LDR_TO_HDR: { v3 r = orc_ldr_to_hdr(V3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+        case ORC_OP_CAMERA: { v3 fwd = V3(a[4], a[5], a[6]), up = V3(a[7], a[8], a[9]);
+            v3 d = orc_camera_ray_dir(a[0], a[1], a[2], a[3], up, fwd, a[10]); o[0] = d.x; o[1] = d.y; o[2] = d.z;
+            orc_camera_pixel(d, a[2], a[3], up, fwd, a[10], &o[3], &o[4]); break; }
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,170 @@
+/*
+ * mq_oracle.h -- CPU ORACLE for the merian-quake hot path (g-buffer first hit -> MCPG surface
+ * estimator -> Markov-chain update application).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load or call it.  The shipped library (libmqhip.so) never
+ * links, includes or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the reference (UnleqitDEV/merian-quake) ships no tests, no golden vectors and
+ * cannot be built here (its `merian` and `quakespasm` submodules are empty, Vulkan ray-query GLSL
+ * cannot run on a CPU).  This file restates the reference's algorithm from its shader / host
+ * sources (cited per function as file:line relative to the reference root).  Every helper that the
+ * reference takes from the absent `merian-shaders` headers (RNG, BSDF, vMF, hash grid, normal
+ * codec, camera, texture sampling) is DEFINED here; those definitions are listed in DESIGN.md
+ * ("Definitions for absent symbols").  The oracle is pinned only by analytic known-answer tests
+ * (tests/test_oracle_kat.py) and by brute-force cross checks, never by reference outputs.
+ *
+ * Plain C11, no dependencies beyond libm/pthreads.
+ */
+#ifndef MQ_ORACLE_H
+#define MQ_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- input layouts: identical to the reference's scene contract ------------------------------ */
+
+/* src/game/quake_helpers.hpp:10-34 / res/shader/scene_info.glsl.h:7-16 (28 bytes) */
+typedef struct {
+    uint16_t texnum_alpha;    /* low 12: texnum, high 4: alpha (0 = use texture alpha, 15 = opaque) */
+    uint16_t texnum_fb_flags; /* low 12: fullbright texnum, high 4: MAT_FLAGS_* */
+    uint32_t n0_gloss_norm;
+    uint32_t n1_brush;
+    uint32_t n2;
+    uint16_t st[6]; /* s0 t0 s1 t1 s2 t2 as IEEE half */
+} orc_ext_t;
+
+/* res/shader/scene_info.glsl.h:18-32 (124 bytes) */
+typedef struct {
+    float cam_x[4];      /* xyz position, w = mu_t */
+    float cam_w[4];      /* xyz forward,  w = time diff */
+    float cam_u[4];      /* xyz up */
+    float prev_cam_x[4]; /* w = mu_s.r */
+    float prev_cam_w[4]; /* w = mu_s.g */
+    float prev_cam_u[4]; /* w = mu_s.b */
+    uint32_t sky_rt_bk, sky_lf_ft, sky_up_dn;
+    float cl_time;
+    uint32_t frame;
+    uint32_t player;
+    uint32_t rt_config;
+} orc_uniform_t;
+
+/* The macro table of src/render_mcpg/render_mcpg.cpp:137-185 plus the g-buffer spec constants of
+ * src/gbuffer/gbuffer.cpp:76-115, as one POD block. */
+typedef struct {
+    int32_t reference_mode;     /* MERIAN_QUAKE_REFERENCE_MODE */
+    int32_t adaptive_grid_type; /* 0 exponential, 1 quadratic */
+    int32_t spp;                /* SURFACE_SPP */
+    int32_t max_path_length;    /* MAX_PATH_LENGTH */
+    int32_t use_light_cache_tail;
+    float fov_tan_alpha_half;
+    float sun_w[3];
+    float sun_color[3];
+    int32_t volume_spp;
+    int32_t volume_use_light_cache;
+    float draine_g, draine_a;
+    int32_t mc_samples;
+    float mc_samples_adaptive_prob;
+    int32_t distance_mc_samples;
+    int32_t mc_fast_recovery;
+    int32_t lc_grid_type;
+    uint32_t lc_buffer_size;
+    float lc_grid_steps_per_unit_size, lc_grid_tan_alpha_half, lc_grid_min_width, lc_grid_power;
+    uint32_t mc_adaptive_buffer_size;
+    float mc_adaptive_grid_tan_alpha_half, mc_adaptive_grid_min_width, mc_adaptive_grid_power,
+        mc_adaptive_grid_steps_per_unit_size;
+    uint32_t mc_static_buffer_size;
+    float mc_static_grid_width;
+    int32_t distance_mc_grid_width;
+    float volume_max_t;
+    float surf_bsdf_p, volume_phase_p, dir_guide_prior, dist_guide_p;
+    uint32_t distance_mc_vertex_state_count;
+    uint32_t seed;
+    /* g-buffer node */
+    int32_t gbuffer_hide_sun; /* src/gbuffer/gbuffer.cpp:99 */
+    /* named quirk switches */
+    int32_t quirk_lc_max_wo_p; /* 1 = keep `max(wo_p, 10)` of mcpg.comp:170 (default) */
+    int32_t quirk_n16_wrap;    /* 1 = wrap N*N to 16 bit as GLSL uint16 arithmetic would (mc.glsl:26) */
+} orc_params_t;
+
+void orc_params_header_defaults(orc_params_t* p); /* src/render_mcpg/render_mcpg.hpp:108-166 */
+void orc_params_json_defaults(orc_params_t* p);   /* res/default_config.json:599-638 */
+
+enum {
+    ORC_GEO_OPAQUE = 1, /* all triangles opaque: no any-hit alpha test (quake_node.cpp:869-871) */
+};
+enum {
+    ORC_TEX_SRGB = 1,   /* decode sRGB -> linear on fetch (quake_node.hpp:93-95) */
+    ORC_TEX_LINEAR = 2, /* bilinear magnification (else nearest) */
+};
+
+enum {
+    ORC_OUT_IRRADIANCE = 0,      /* mcpg: RGBA32F rgb = mean radiance, a = second moment */
+    ORC_OUT_GB_ALBEDO = 1,       /* gbuffer: RGBA16F */
+    ORC_OUT_GB_IRRADIANCE = 2,   /* gbuffer: RGBA16F first-hit emission */
+    ORC_OUT_GB_MV = 3,           /* gbuffer: RG16F */
+    ORC_OUT_GBUFFER = 4,         /* 16 B/px: enc_normal u32, linear_z f32, grad_z 2xf16, vel_z f32 */
+    ORC_OUT_HITS = 5,            /* 40 B/px CompressedHit (res/shader/hit.glsl.h:19-30) */
+    ORC_OUT_COUNT
+};
+
+typedef struct {
+    uint64_t rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
+        mc_updates_dropped, mc_state_reads;
+} orc_counters_t;
+
+typedef struct orc_ctx orc_ctx;
+
+orc_ctx* orc_create(const orc_params_t* p);
+void orc_destroy(orc_ctx* c);
+int orc_set_params(orc_ctx* c, const orc_params_t* p);
+int orc_set_geometry(orc_ctx* c, int slot, const float* vtx, const float* prev_vtx, uint32_t n_vtx,
+                     const uint32_t* idx, const orc_ext_t* ext, uint32_t n_tri, uint32_t flags);
+int orc_set_texture(orc_ctx* c, uint32_t texnum, uint32_t w, uint32_t h, const uint8_t* rgba8,
+                    uint32_t flags);
+/* accel: 0 = brute force over all triangles, 1 = plain binary median-split BVH */
+int orc_commit(orc_ctx* c, int accel);
+/* allocate + zero all state (render_mcpg.cpp:221-226) for a W x H frame */
+int orc_connect(orc_ctx* c, uint32_t w, uint32_t h);
+/* one frame: g-buffer pass, surface pass, update pass (render_mcpg.cpp:243-277).
+ * threads > 1 is only deterministic in reference mode. */
+int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads);
+const void* orc_output(orc_ctx* c, int which, size_t* bytes);
+void orc_get_counters(orc_ctx* c, orc_counters_t* out, int reset);
+
+/* closest-hit queries (raytrace.glsl:82-119 semantics: back-face cull, alpha any-hit, tmin 0,
+ * tmax 1e4).  out_prim = (slot << 28 | prim) or 0xffffffff on miss. */
+int orc_trace_rays(orc_ctx* c, const float* org, const float* dir, uint32_t n, uint32_t* out_prim,
+                   float* out_t, float* out_uv);
+
+/* scalar math / shading known-answer entry points; `op` values below. in/out are float arrays,
+ * n elements of `arity` inputs each. */
+enum {
+    ORC_OP_EXP2 = 0,      /* 1 -> 1 */
+    ORC_OP_LOG2 = 1,      /* 1 -> 1 */
+    ORC_OP_SINCOS2PI = 2, /* 1 -> 2 */
+    ORC_OP_POW = 3,       /* 2 -> 1 */
+    ORC_OP_F2H2F = 4,     /* 1 -> 1 round trip through half */
+    ORC_OP_ENC_DEC_NORMAL = 5, /* 3 -> 4 (decoded xyz, encoded bits as float-punned u32) */
+    ORC_OP_BSDF_SAMPLE = 6, /* wi3 n3 rough xi3 (10) -> wo3 pdf value (5) */
+    ORC_OP_VMF_SAMPLE = 7,  /* mu3 kappa xi2 (6) -> w3 pdf (4) */
+    ORC_OP_XORSHIFT = 8,    /* seed-as-float-punned (1) -> 4 successive uniforms (4) */
+    ORC_OP_PCG4D16 = 9,     /* 4 punned u32 -> 1 punned u32 */
+    ORC_OP_SKY = 10,        /* w3 (3) -> rgb (3); uses ctx params, no sky textures */
+    ORC_OP_HASHGRID = 11,   /* pos3 normal3 level width-as-float size-punned (9) -> idx, chk punned (2) */
+    ORC_OP_LDR_TO_HDR = 12, /* 3 -> 3 */
+    ORC_OP_CAMERA = 13,     /* px py W H fwd3 up3 tan (11) -> dir3 + pixel2 roundtrip (5) */
+    ORC_OP_COUNT
+};
+int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n);
+int orc_op_arity(int op, int* n_in, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,194 @@
+"""ctypes binding of the CPU oracle (oracle/libmqoracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "libmqoracle.so")
+
+(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS) = range(6)
+(OP_EXP2, OP_LOG2, OP_SINCOS2PI, OP_POW, OP_F2H2F, OP_ENC_DEC_NORMAL, OP_BSDF_SAMPLE, OP_VMF_SAMPLE, OP_XORSHIFT,
+ OP_PCG4D16, OP_SKY, OP_HASHGRID, OP_LDR_TO_HDR, OP_CAMERA) = range(14)
+OP_ARITY = {0: (1, 1), 1: (1, 1), 2: (1, 2), 3: (2, 1), 4: (1, 1), 5: (3, 4), 6: (10, 5), 7: (6, 4), 8: (1, 4), 9: (4, 1),
+            10: (3, 3), 11: (9, 2), 12: (3, 3), 13: (11, 5)}
+
+
+class Params(C.Structure):
+    _fields_ = [("reference_mode", C.c_int32), ("adaptive_grid_type", C.c_int32), ("spp", C.c_int32),
+                ("max_path_length", C.c_int32), ("use_light_cache_tail", C.c_int32), ("fov_tan_alpha_half", C.c_float),
+                ("sun_w", C.c_float * 3), ("sun_color", C.c_float * 3), ("volume_spp", C.c_int32),
+                ("volume_use_light_cache", C.c_int32), ("draine_g", C.c_float), ("draine_a", C.c_float),
+                ("mc_samples", C.c_int32), ("mc_samples_adaptive_prob", C.c_float), ("distance_mc_samples", C.c_int32),
+                ("mc_fast_recovery", C.c_int32), ("lc_grid_type", C.c_int32), ("lc_buffer_size", C.c_uint32),
+                ("lc_grid_steps_per_unit_size", C.c_float), ("lc_grid_tan_alpha_half", C.c_float),
+                ("lc_grid_min_width", C.c_float), ("lc_grid_power", C.c_float), ("mc_adaptive_buffer_size", C.c_uint32),
+                ("mc_adaptive_grid_tan_alpha_half", C.c_float), ("mc_adaptive_grid_min_width", C.c_float),
+                ("mc_adaptive_grid_power", C.c_float), ("mc_adaptive_grid_steps_per_unit_size", C.c_float),
+                ("mc_static_buffer_size", C.c_uint32), ("mc_static_grid_width", C.c_float),
+                ("distance_mc_grid_width", C.c_int32), ("volume_max_t", C.c_float), ("surf_bsdf_p", C.c_float),
+                ("volume_phase_p", C.c_float), ("dir_guide_prior", C.c_float), ("dist_guide_p", C.c_float),
+                ("distance_mc_vertex_state_count", C.c_uint32), ("seed", C.c_uint32), ("gbuffer_hide_sun", C.c_int32),
+                ("quirk_lc_max_wo_p", C.c_int32), ("quirk_n16_wrap", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "tris", "segments", "guided_segments", "lc_touches",
+                                          "mc_updates_accepted", "mc_updates_dropped", "mc_state_reads")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = C.CDLL(LIB)
+        P = C.c_void_p
+        l.orc_create.restype = P
+        l.orc_create.argtypes = [C.POINTER(Params)]
+        l.orc_destroy.argtypes = [P]
+        l.orc_set_params.argtypes = [P, C.POINTER(Params)]
+        l.orc_set_geometry.argtypes = [P, C.c_int, P, P, C.c_uint32, P, P, C.c_uint32, C.c_uint32]
+        l.orc_set_texture.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_uint32]
+        l.orc_commit.argtypes = [P, C.c_int]
+        l.orc_connect.argtypes = [P, C.c_uint32, C.c_uint32]
+        l.orc_process.argtypes = [P, P, C.c_int, C.c_int]
+        l.orc_output.restype = P
+        l.orc_output.argtypes = [P, C.c_int, C.POINTER(C.c_size_t)]
+        l.orc_get_counters.argtypes = [P, C.POINTER(Counters), C.c_int]
+        l.orc_trace_rays.argtypes = [P, P, P, C.c_uint32, P, P, P]
+        l.orc_math_eval.argtypes = [P, C.c_int, P, P, C.c_uint32]
+        l.orc_params_header_defaults.argtypes = [C.POINTER(Params)]
+        l.orc_params_json_defaults.argtypes = [C.POINTER(Params)]
+        _lib = l
+    return _lib
+
+
+def header_params():
+    p = Params()
+    lib().orc_params_header_defaults(C.byref(p))
+    return p
+
+
+def json_params():
+    p = Params()
+    lib().orc_params_json_defaults(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, params=None):
+        self.l = lib()
+        self.params = params or header_params()
+        self.h = C.c_void_p(self.l.orc_create(C.byref(self.params)))
+
+    def close(self):
+        if self.h:
+            self.l.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, p):
+        self.params = p
+        self.l.orc_set_params(self.h, C.byref(p))
+
+    def set_geometry(self, slot, vtx, prev_vtx, idx, ext, flags):
+        vtx = np.ascontiguousarray(vtx, np.float32)
+        prev = None if prev_vtx is None else np.ascontiguousarray(prev_vtx, np.float32)
+        idx = np.ascontiguousarray(idx, np.uint32)
+        ext = np.ascontiguousarray(ext)
+        assert ext.dtype.itemsize == 28
+        r = self.l.orc_set_geometry(self.h, slot, _ptr(vtx), _ptr(prev), vtx.size // 3, _ptr(idx), _ptr(ext), idx.size // 3, flags)
+        assert r == 0, r
+
+    def set_texture(self, texnum, rgba8, flags):
+        rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+        h, w = rgba8.shape[:2]
+        assert self.l.orc_set_texture(self.h, texnum, w, h, _ptr(rgba8), flags) == 0
+
+    def commit(self, accel=1):
+        assert self.l.orc_commit(self.h, accel) == 0
+
+    def connect(self, w, h):
+        assert self.l.orc_connect(self.h, w, h) == 0
+        self.W, self.H = w, h
+
+    def process(self, uniform, render=True, threads=1):
+        assert self.l.orc_process(self.h, C.addressof(uniform), 1 if render else 0, threads) == 0
+
+    def output(self, which):
+        n = C.c_size_t()
+        p = self.l.orc_output(self.h, which, C.byref(n))
+        return np.frombuffer((C.c_char * n.value).from_address(p), dtype=np.uint8).copy()
+
+    def irradiance(self):
+        return self.output(OUT_IRRADIANCE).view(np.float32).reshape(self.H, self.W, 4)
+
+    def counters(self, reset=False):
+        c = Counters()
+        self.l.orc_get_counters(self.h, C.byref(c), 1 if reset else 0)
+        return {n: int(getattr(c, n)) for n, _ in c._fields_}
+
+    def trace_rays(self, org, direction):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, np.float32).reshape(-1, 3)
+        n = len(org)
+        prim, t, uv = np.empty(n, np.uint32), np.empty(n, np.float32), np.empty((n, 2), np.float32)
+        self.l.orc_trace_rays(self.h, _ptr(org), _ptr(direction), n, _ptr(prim), _ptr(t), _ptr(uv))
+        return prim, t, uv
+
+    def math_eval(self, op, inp):
+        inp = np.ascontiguousarray(inp, np.float32)
+        n = inp.shape[0]
+        out = np.empty((n, OP_ARITY[op][1]), np.float32)
+        assert self.l.orc_math_eval(self.h, op, _ptr(inp), _ptr(out), n) == 0
+        return out
+
+
+def params_from_ctx(ctx, constants=None):
+    """Build oracle params from a product context's property table (same keys, same values)."""
+    p = header_params()
+    g = ctx.get_property
+    p.reference_mode = int(g("reference mode") or g("BSDF Prob") == 1.0)
+    p.adaptive_grid_type = int(g("adaptive grid type")); p.spp = int(g("spp")); p.max_path_length = int(g("max path length"))
+    p.use_light_cache_tail = int(g("surf: use LC")); p.mc_samples = int(g("mc samples"))
+    p.mc_samples_adaptive_prob = g("adaptive grid prob"); p.mc_fast_recovery = int(g("mc fast recovery"))
+    p.lc_grid_type = int(g("LC grid type")); p.lc_buffer_size = int(g("LC buf size"))
+    p.lc_grid_steps_per_unit_size = g("LC grid steps per unit"); p.lc_grid_tan_alpha_half = g("LC grid tan(alpha/2)")
+    p.lc_grid_min_width = g("LC grid min width"); p.lc_grid_power = g("LC grid power")
+    p.mc_adaptive_buffer_size = int(g("adaptive grid buf size")); p.mc_adaptive_grid_tan_alpha_half = g("adaptive grid tan(alpha/2)")
+    p.mc_adaptive_grid_min_width = g("adaptive grid min width"); p.mc_adaptive_grid_power = g("adaptive grid power")
+    p.mc_adaptive_grid_steps_per_unit_size = g("adaptive grid steps per unit")
+    p.mc_static_buffer_size = int(g("static grid buf size")); p.mc_static_grid_width = g("mc static width")
+    p.surf_bsdf_p = g("BSDF Prob"); p.dir_guide_prior = g("ML Prior"); p.seed = int(g("seed"))
+    p.gbuffer_hide_sun = int(g("hide sun")); p.quirk_lc_max_wo_p = int(g("quirk: LC max(wo_p,10)")); p.quirk_n16_wrap = int(g("quirk: 16-bit N*N"))
+    if constants is not None:
+        for k in range(3):
+            p.sun_w[k] = constants["sun_direction"][k]
+            p.sun_color[k] = constants["sun_color"][k]
+        p.fov_tan_alpha_half = constants["fov_tan_alpha_half"]
+        p.volume_max_t = constants["volume_max_t"]
+    return p
+
+
+def mirror_scene(ctx, oracle):
+    """Copy geometry + textures held by a product context into the oracle (scene data is input, not algorithm)."""
+    for slot in range(16):
+        g = ctx.get_geometry(slot)
+        if g is None:
+            continue
+        oracle.set_geometry(slot, g["vtx"], g["prev_vtx"], g["idx"], g["ext"], 1 if (g["flags"] & 1) else 0)
+    for t in range(4096):
+        tx = ctx.get_texture(t)
+        if tx is not None:
+            oracle.set_texture(t, tx[0], tx[1])
