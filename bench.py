@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the HIP path: Msamples/s at 1920x1080 1 spp, MCPG guiding on.
+
+A "step" is one frame of the hot path (primary ray + guided surface estimator + Markov-chain
+update application) over the whole 1920x1080 framebuffer.  With --gpus N the framebuffer's 8x8
+tiles are dealt round-robin to the N ranks (one process per GPU), each rank renders its tiles with
+its own scene/BVH replica and its own learning state, and one RCCL all-gather of the RGBA32F
+radiance tiles rebuilds the full image on every rank: total work is fixed, so the
+scaling is "strong".
+
+Workload: the reference's `ad_sepulcher` map is not available offline (no Quake data in the image),
+so the seeded synthetic stand-in `synth_sepulcher(seed=2)` is rendered with the
+shipped JSON renderer defaults (res/default_config.json:599-638) except spp=1, fixed seed.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of the render megakernel
+per launch (counted by an instrumented launch of the same kernel on the same frame)
+divided by its average launch duration measured with HIP events on the launch stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes(c, pixels):
+    """B = P*(40+16) + sum_rays(80 n_nodes + 48 n_tris + 120) + guided segs*(K*64) + 24*lc + U*192."""
+    return (pixels * 56 + 80 * c["nodes"] + 48 * c["tris"] + 120 * c["rays"] + 64 * c["mc_state_reads"]
+            + 24 * c["lc_touches"] + 192 * c["mc_updates_accepted"])
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch.as_tensor (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(ctx, scene, seed, props, W, H, warm, timed):
+    """Naive CPU path tracer (the oracle: plain binary BVH, scalar code, all host cores) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    cores = os.cpu_count() or 1
+    p = orc.params_from_ctx(ctx, ctx.get_constants())
+    o = orc.Oracle(p)
+    orc.mirror_scene(ctx, o)
+    o.commit(1)
+    o.connect(W, H)
+    for f in range(warm):
+        o.process(ctx.synth_camera(f), threads=cores)
+    t0 = time.perf_counter()
+    for f in range(warm, warm + timed):
+        o.process(ctx.synth_camera(f), threads=cores)
+    dt = time.perf_counter() - t0
+    spp = int(ctx.get_property("spp"))
+    val = W * H * spp * timed / dt / 1e6
+    o.close()
+    return {"value": round(val, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d (same scene, camera, parameters), %d warm-up + %d timed guided frames, plain binary BVH, %d pthreads" % (W, H, warm, timed, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="synth_sepulcher")
+    ap.add_argument("--scene-seed", type=int, default=2)
+    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--reference-mode", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mqhip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+
+    W, H = args.width, args.height
+    ctx = mqhip.Context(local_rank)
+    ctx.json_defaults()
+    props = {"randomize seed": 0, "seed": 0x5EED, "spp": args.spp, "max path length": 3, "reference mode": args.reference_mode}
+    for k, v in props.items():
+        ctx.set_property(k, v)
+    ctx.synth_scene(args.scene, args.scene_seed)
+    ctx.commit()
+    ctx.set_partition(rank, world)
+    ctx.connect(W, H)
+    stats = ctx.scene_stats()
+    stream = torch.cuda.current_stream().cuda_stream
+    tiles, tile_bytes = ctx.tiles_per_rank()
+    tiles_ptr, _ = ctx.map_output(mqhip.OUT_TILES)
+    local = gathered = None
+    if world > 1:
+        local = torch.as_tensor(_DevArray(tiles_ptr, tile_bytes // 4), device="cuda")
+        gathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
+
+    def step(frame):
+        ctx.process(ctx.synth_camera(frame), True, stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, local)  # the one exchange step: RCCL over xGMI
+            ctx.untile(gathered.data_ptr(), stream)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    frame = 0
+    for _ in range(args.warmup):
+        step(frame); frame += 1
+    sync_all()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(frame); frame += 1
+    sync_all()
+    dt = time.perf_counter() - t0
+    # device time of the render megakernel, averaged over exactly the timed launches (hipEvents
+    # recorded on the launch stream inside mq_process)
+    n_timed, render_sum, update_sum = ctx.timing_get()
+    assert n_timed == args.steps
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = W * H * args.spp * args.steps / dt / 1e6
+
+    # algorithmic bytes: one instrumented launch of the same kernel on the next frame
+    ctx.enable_counters(True)
+    step(frame); frame += 1
+    torch.cuda.synchronize()
+    c = ctx.counters()
+    ctx.enable_counters(False)
+    local_pixels = c["pixels"]
+    B = algorithmic_bytes(c, local_pixels)
+    avg_render_ms = render_sum / n_timed
+    achieved = B / (avg_render_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "mq_render_kernel<guided>" if not args.reference_mode else "mq_render_kernel<reference>",
+                "kernel_ms": round(avg_render_ms, 4), "update_kernel_ms": round(update_sum / n_timed, 4), "algorithmic_bytes_per_launch": int(B),
+                "bytes_per_sample": round(B / max(1, local_pixels * args.spp), 1), "counters": c}
+
+    out = {"metric": "Msamples/s at 1920x1080 1spp (ad_sepulcher); per-pixel L2 vs reference", "value": round(value, 3),
+           "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s(seed=%d) stand-in for ad_sepulcher, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
+                                  % (args.scene, args.scene_seed, W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
+                      "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world,
+                      "collective": "none" if world == 1 else "1x RCCL all_gather of %d B/rank per frame" % tile_bytes},
+           "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ctx, args.scene, args.scene_seed, props, 480, 270, 4, 4)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,6 +165,11 @@ int mq_map_output(mq_ctx* ctx, int which, void** dev_ptr, size_t* bytes);
 int mq_read_output(mq_ctx* ctx, int which, void* host_dst, size_t bytes); /* sync + D2H copy */
 /* device time of the last frame's hot-path kernels (hipEvent pair on the process stream) */
 int mq_last_frame_ms(mq_ctx* ctx, float* total_ms, float* render_ms, float* update_ms);
+/* accumulated device time of every frame since the last reset (hipEvent triplets recorded on the
+ * process stream, resolved lazily so frames stay in flight): MERIAN_PROFILE_SCOPE_GPU "surface",
+ * render_mcpg.cpp:255 */
+int mq_timing_reset(mq_ctx* ctx);
+int mq_timing_get(mq_ctx* ctx, uint32_t* frames, double* render_ms_sum, double* update_ms_sum);
 /* enable work counting for subsequent frames (separate kernel instantiation, slower) */
 int mq_enable_counters(mq_ctx* ctx, int on);
 int mq_get_counters(mq_ctx* ctx, mq_counters* out);

@@ -66,7 +66,12 @@ struct mq_ctx {
     MqParams params{};
     bool count_enabled = false;
     int cu_count = 0, grid_blocks = 0;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    static const int EV_RING = 64;
+    hipEvent_t evr[EV_RING][3] = {};
+    bool ev_pending[EV_RING] = {};
+    int ev_slot = 0, ev_last = -1;
+    double t_render_sum = 0.0, t_update_sum = 0.0; uint32_t t_frames = 0;
+    float last_render_ms = 0.0f, last_update_ms = 0.0f;
     bool ev_valid = false;
     hipStream_t last_stream = nullptr;
     mq_ctx() : tex(MQ_MAX_GLTEXTURES) {}
@@ -308,7 +313,7 @@ int mq_create(mq_ctx** out, int device) {
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return MQ_ENODEVICE; }
         c->cu_count = prop.multiProcessorCount;
         c->device = device;
-        for (auto& e3 : c->ev) if (hipEventCreate(&e3) != hipSuccess) { delete c; return MQ_EHIP; }
+        for (auto& tr : c->evr) for (auto& e3 : tr) if (hipEventCreate(&e3) != hipSuccess) { delete c; return MQ_EHIP; }
     }
     *out = c;
     return MQ_OK;
@@ -320,7 +325,7 @@ void mq_destroy(mq_ctx* c) {
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();
         free_frame_state(c); free_scene_dev(c);
-        for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+        for (auto& tr : c->evr) for (auto& e : tr) if (e) (void)hipEventDestroy(e);
     }
     delete c;
 }
@@ -576,6 +581,18 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     return MQ_OK;
 }
 
+static int drain_slot(mq_ctx* c, int slot) {
+    if (!c->ev_pending[slot]) return MQ_OK;
+    HIPCHK(c, hipEventSynchronize(c->evr[slot][2]));
+    float a = 0, b = 0;
+    HIPCHK(c, hipEventElapsedTime(&a, c->evr[slot][0], c->evr[slot][1]));
+    HIPCHK(c, hipEventElapsedTime(&b, c->evr[slot][1], c->evr[slot][2]));
+    c->t_render_sum += a; c->t_update_sum += b; c->t_frames++;
+    if (slot == c->ev_last) { c->last_render_ms = a; c->last_update_ms = b; }
+    c->ev_pending[slot] = false;
+    return MQ_OK;
+}
+
 int mq_reset_state(mq_ctx* c) { if (!c) return MQ_EINVAL; c->iteration = 0; return MQ_OK; }
 
 static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
@@ -610,21 +627,23 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     if (!render) { // render_mcpg.cpp:243-250
         int e = mq_launch_clear(F, s);
         if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
-        c->ev_valid = false;
         return MQ_OK;
     }
     HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, 64, s));
     if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(MqCountersDev), s));
     const bool guided = !c->params.reference_mode;
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    const int slot = c->ev_slot;
+    { int r = drain_slot(c, slot); if (r) return r; } // the slot's previous frame finished long ago
+    HIPCHK(c, hipEventRecord(c->evr[slot][0], s));
     int e = mq_launch_render(c->scene, c->params, F, guided, c->count_enabled, c->grid_blocks, s);
     if (e) return fail(c, MQ_EHIP, std::string("render launch: ") + hipGetErrorString((hipError_t)e));
-    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    HIPCHK(c, hipEventRecord(c->evr[slot][1], s));
     if (guided) { // render_mcpg.cpp:261-277
         e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, s);
         if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     }
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    HIPCHK(c, hipEventRecord(c->evr[slot][2], s));
+    c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
     c->ev_valid = true;
     return MQ_OK;
 }
@@ -655,12 +674,23 @@ int mq_read_output(mq_ctx* c, int which, void* dst, size_t bytes) {
 int mq_last_frame_ms(mq_ctx* c, float* total_ms, float* render_ms, float* update_ms) {
     if (!c) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
-    if (!c->ev_valid) return fail(c, MQ_ESTATE, "no timed frame yet");
-    HIPCHK(c, hipEventSynchronize(c->ev[2]));
-    float a = 0, b = 0;
-    HIPCHK(c, hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-    HIPCHK(c, hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
-    if (render_ms) *render_ms = a; if (update_ms) *update_ms = b; if (total_ms) *total_ms = a + b;
+    if (!c->ev_valid || c->ev_last < 0) return fail(c, MQ_ESTATE, "no timed frame yet");
+    { int r = drain_slot(c, c->ev_last); if (r) return r; }
+    if (render_ms) *render_ms = c->last_render_ms; if (update_ms) *update_ms = c->last_update_ms; if (total_ms) *total_ms = c->last_render_ms + c->last_update_ms;
+    return MQ_OK;
+}
+int mq_timing_reset(mq_ctx* c) {
+    if (!c) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
+    c->t_render_sum = c->t_update_sum = 0.0; c->t_frames = 0;
+    return MQ_OK;
+}
+int mq_timing_get(mq_ctx* c, uint32_t* frames, double* render_ms_sum, double* update_ms_sum) {
+    if (!c) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
+    if (frames) *frames = c->t_frames; if (render_ms_sum) *render_ms_sum = c->t_render_sum; if (update_ms_sum) *update_ms_sum = c->t_update_sum;
     return MQ_OK;
 }
 int mq_enable_counters(mq_ctx* c, int on) { if (!c) return MQ_EINVAL; c->count_enabled = on != 0; return MQ_OK; }

@@ -193,16 +193,13 @@ MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, float tmax, RayHit& hit, 
             const uint4* tp = (const uint4*)(sc.tris + (tbase + k));
             uint4 a = tp[0], b = tp[1], c = tp[2];
             if (COUNT) ctr.tris++;
-            float t, u, v;
-            if (!tri_isect(o, d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
-                           F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
-                           F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), t, u, v))
-                continue;
-            if (!(t < tmax)) continue;
-            if (t < hit.t || (t == hit.t && c.y < best_key)) {
-                if ((c.z & MQ_TRI_ANYHIT) && !anyhit_confirm(sc, c.y, u, v)) continue;
-                hit.t = t; hit.u = u; hit.v = v; hit.tri = tbase + k; best_key = c.y;
-            }
+            float t = 0.0f, u = 0.0f, v = 0.0f;
+            bool accept = tri_isect(o, d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
+                                    F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
+                                    F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), t, u, v);
+            accept = accept && (t < tmax) && (t < hit.t || (t == hit.t && c.y < best_key));
+            if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, c.y, u, v);
+            if (accept) { hit.t = t; hit.u = u; hit.v = v; hit.tri = tbase + k; best_key = c.y; }
         }
         if (G.y <= 0x00ffffffu) {
             if (sp == 0) break;

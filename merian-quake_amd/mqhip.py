@@ -94,6 +94,8 @@ def load_library(path=None):
         "mq_map_output": (i32, [P, i32, C.POINTER(vp), C.POINTER(sz)]),
         "mq_read_output": (i32, [P, i32, vp, sz]),
         "mq_last_frame_ms": (i32, [P, f32p, f32p, f32p]),
+        "mq_timing_reset": (i32, [P]),
+        "mq_timing_get": (i32, [P, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mq_enable_counters": (i32, [P, i32]),
         "mq_get_counters": (i32, [P, C.POINTER(Counters)]),
         "mq_reset_state": (i32, [P]),
@@ -265,6 +267,14 @@ class Context:
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         self._chk(self.lib.mq_last_frame_ms(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def timing_reset(self):
+        self._chk(self.lib.mq_timing_reset(self.h))
+
+    def timing_get(self):
+        n, a, b = C.c_uint32(), C.c_double(), C.c_double()
+        self._chk(self.lib.mq_timing_get(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value
 
     def enable_counters(self, on):
         self._chk(self.lib.mq_enable_counters(self.h, 1 if on else 0))
