@@ -151,6 +151,8 @@ int mq_scene_get_geometry(const mq_ctx* ctx, int slot, const float** vtx, const 
                           uint32_t* flags);
 int mq_scene_get_texture(const mq_ctx* ctx, uint32_t texnum, uint32_t* w, uint32_t* h,
                          const uint8_t** rgba8, uint32_t* flags);
+/* committed acceleration structure, for inspection: 80-byte nodes, 48-byte triangles (leaf order) */
+int mq_scene_get_bvh(const mq_ctx* ctx, const void** nodes, uint64_t* n_nodes, const void** tris, uint64_t* n_tris);
 int mq_scene_stats(const mq_ctx* ctx, uint64_t* n_tris, uint64_t* n_nodes, uint64_t* bvh_bytes,
                    float* sah_cost);
 

@@ -453,6 +453,12 @@ int mq_scene_get_texture(const mq_ctx* c, uint32_t texnum, uint32_t* w, uint32_t
     if (w) *w = t.w; if (h) *h = t.h; if (rgba8) *rgba8 = t.px.empty() ? nullptr : t.px.data(); if (flags) *flags = t.flags;
     return MQ_OK;
 }
+int mq_scene_get_bvh(const mq_ctx* c, const void** nodes, uint64_t* n_nodes, const void** tris, uint64_t* n_tris) {
+    if (!c) return MQ_EINVAL;
+    if (!c->committed) return MQ_ESTATE;
+    if (nodes) *nodes = c->nodes.data(); if (n_nodes) *n_nodes = c->nodes.size(); if (tris) *tris = c->tris.data(); if (n_tris) *n_tris = c->tris.size();
+    return MQ_OK;
+}
 int mq_scene_stats(const mq_ctx* c, uint64_t* n_tris, uint64_t* n_nodes, uint64_t* bvh_bytes, float* sah_cost) {
     if (!c) return MQ_EINVAL;
     if (n_tris) *n_tris = c->tris.size(); if (n_nodes) *n_nodes = c->nodes.size();

@@ -137,13 +137,13 @@ MQ_DEV uint32_t encode_normal(f3 n) {
         float ty = (1.0f - fabsf(px)) * sgn1(py);
         px = tx; py = ty;
     }
-    float fx = floorf(mclamp(px * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
-    float fy = floorf(mclamp(py * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
-    return (uint32_t)fx | ((uint32_t)fy << 16);
+    int qx = (int)floorf(mclamp(px, -1.0f, 1.0f) * 32767.0f + 0.5f);
+    int qy = (int)floorf(mclamp(py, -1.0f, 1.0f) * 32767.0f + 0.5f);
+    return ((uint32_t)qx & 0xffffu) | (((uint32_t)qy & 0xffffu) << 16);
 }
 MQ_DEV f3 decode_normal(uint32_t e) {
-    float px = (float)(e & 0xffffu) * (2.0f / 65535.0f) - 1.0f;
-    float py = (float)(e >> 16) * (2.0f / 65535.0f) - 1.0f;
+    float px = (float)(int16_t)(e & 0xffffu) * (1.0f / 32767.0f);
+    float py = (float)(int16_t)(e >> 16) * (1.0f / 32767.0f);
     float pz = 1.0f - fabsf(px) - fabsf(py);
     if (pz < 0.0f) {
         float tx = (1.0f - fabsf(py)) * sgn1(px);
@@ -241,8 +241,11 @@ MQ_DEV float bsdf_times_wodotn(f3 wi, f3 wo, f3 n, float alpha, float F0) {
     float m = 1.0f - vdoth;
     float m2 = m * m;
     float F = F0 + (1.0f - F0) * (m2 * m2 * m);
+    float mv = 1.0f - ndotv;
+    float mv2 = mv * mv;
+    float Fv = F0 + (1.0f - F0) * (mv2 * mv2 * mv);
     float spec = F * ggx_D(ndoth, alpha) * ggx_G1(ndotv, alpha) * ggx_G1(ndoto, alpha) / (4.0f * ndotv * ndoto);
-    return ((1.0f - F) * MQ_INV_PI + spec) * ndoto;
+    return ((1.0f - Fv) * MQ_INV_PI + spec) * ndoto;
 }
 
 // ---- hash grid ------------------------------------------------------------------------------

@@ -23,6 +23,10 @@ MQ_ENODEVICE = -2
 EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),
                       ("n1_brush", "<u4"), ("n2", "<u4"), ("st", "<u2", (6,))])
 assert EXT_DTYPE.itemsize == 28
+NODE_DTYPE = np.dtype([("p", "<f4", (3,)), ("e", "u1", (3,)), ("imask", "u1"), ("child_base", "<u4"), ("tri_base", "<u4"),
+                       ("meta", "u1", (8,)), ("qlo", "u1", (3, 8)), ("qhi", "u1", (3, 8))])
+TRI_DTYPE = np.dtype([("v", "<f4", (3, 3)), ("key", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
+assert NODE_DTYPE.itemsize == 80 and TRI_DTYPE.itemsize == 48
 
 
 class Uniform(C.Structure):
@@ -86,6 +90,7 @@ def load_library(path=None):
         "mq_get_constants": (i32, [P, C.POINTER(Constants)]),
         "mq_scene_get_geometry": (i32, [P, i32, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(vp), C.POINTER(vp), u32p, u32p]),
         "mq_scene_get_texture": (i32, [P, u32, u32p, u32p, C.POINTER(vp), u32p]),
+        "mq_scene_get_bvh": (i32, [P, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "mq_scene_stats": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]),
         "mq_describe": (i32, [P, u32, u32, C.POINTER(IoDesc)]),
         "mq_connect": (i32, [P, u32, u32]),
@@ -215,6 +220,14 @@ class Context:
             return None
         px = np.frombuffer((C.c_char * (w.value * h.value * 4)).from_address(p.value), dtype=np.uint8).copy().reshape(h.value, w.value, 4)
         return px, fl.value
+
+    def get_bvh(self):
+        n, t = C.c_void_p(), C.c_void_p()
+        nn, nt = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.mq_scene_get_bvh(self.h, C.byref(n), C.byref(nn), C.byref(t), C.byref(nt)))
+        nodes = np.frombuffer((C.c_char * (nn.value * 80)).from_address(n.value), dtype=NODE_DTYPE).copy() if nn.value else np.empty(0, NODE_DTYPE)
+        tris = np.frombuffer((C.c_char * (nt.value * 48)).from_address(t.value), dtype=TRI_DTYPE).copy() if nt.value else np.empty(0, TRI_DTYPE)
+        return nodes, tris
 
     def scene_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

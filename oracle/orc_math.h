@@ -187,13 +187,14 @@ static inline uint32_t orc_encode_normal(v3 n) {
         float ty = (1.0f - fabsf(px)) * orc_sgn(py);
         px = tx; py = ty;
     }
-    float fx = floorf(oclamp(px * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
-    float fy = floorf(oclamp(py * 0.5f + 0.5f, 0.0f, 1.0f) * 65535.0f + 0.5f);
-    return (uint32_t)fx | ((uint32_t)fy << 16);
+    /* snorm16 per axis: 0 and +-1 are exact, so axis-aligned normals survive the codec bit for bit */
+    int qx = (int)floorf(oclamp(px, -1.0f, 1.0f) * 32767.0f + 0.5f);
+    int qy = (int)floorf(oclamp(py, -1.0f, 1.0f) * 32767.0f + 0.5f);
+    return ((uint32_t)qx & 0xffffu) | (((uint32_t)qy & 0xffffu) << 16);
 }
 static inline v3 orc_decode_normal(uint32_t e) {
-    float px = (float)(e & 0xffffu) * (2.0f / 65535.0f) - 1.0f;
-    float py = (float)(e >> 16) * (2.0f / 65535.0f) - 1.0f;
+    float px = (float)(int16_t)(e & 0xffffu) * (1.0f / 32767.0f);
+    float py = (float)(int16_t)(e >> 16) * (1.0f / 32767.0f);
     float pz = 1.0f - fabsf(px) - fabsf(py);
     if (pz < 0.0f) {
         float tx = (1.0f - fabsf(py)) * orc_sgn(px);
@@ -283,7 +284,7 @@ static inline float orc_bsdf_pdf(v3 wi, v3 wo, v3 n, float alpha) {
     if (!(ndoth > 0.0f) || !(vdoth > 0.0f)) return pd;
     return pd + 0.5f * orc_ggx_D(ndoth, alpha) * ndoth / (4.0f * vdoth);
 }
-/* ((1-F)/pi + F D G / (4 (n.v)(n.o))) * (n.o), Schlick F with F0; albedo excluded */
+/* ((1-F(n.v))/pi + F(v.h) D G / (4 (n.v)(n.o))) * (n.o), Schlick F with F0; albedo excluded */
 static inline float orc_bsdf_times_wodotn(v3 wi, v3 wo, v3 n, float alpha, float F0) {
     float ndoto = vdot(n, wo);
     v3 v = vneg(wi);
@@ -297,9 +298,12 @@ static inline float orc_bsdf_times_wodotn(v3 wi, v3 wo, v3 n, float alpha, float
     float m = 1.0f - vdoth;
     float m2 = m * m;
     float F = F0 + (1.0f - F0) * (m2 * m2 * m);
+    float mv = 1.0f - ndotv;
+    float mv2 = mv * mv;
+    float Fv = F0 + (1.0f - F0) * (mv2 * mv2 * mv); /* view-dependent Fresnel gates the diffuse lobe */
     float spec = F * orc_ggx_D(ndoth, alpha) * orc_ggx_G1(ndotv, alpha) * orc_ggx_G1(ndoto, alpha) /
                  (4.0f * ndotv * ndoto);
-    return ((1.0f - F) * ORC_INV_PI + spec) * ndoto;
+    return ((1.0f - Fv) * ORC_INV_PI + spec) * ndoto;
 }
 
 /* ---- hash grid (merian-shaders/grid.glsl + hash.glsl, DEFINED) ------------------------------- */

@@ -1,0 +1,275 @@
+"""CPU tests of the host side of libmqhip: the C ABI surface, the reference's property table, the
+scene sources (synthetic generator, BSP29/BSP2 loader) and the BVH builder.  No GPU compute: a
+host-only context must refuse every device entry point with MQ_ENODEVICE (there is no CPU path)."""
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mq(mqlib):
+    import mqhip
+    return mqhip
+
+
+def test_library_exports_every_declared_symbol(mq, mqlib):
+    hdr = open(os.path.join(ROOT, "include", "mq.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(mq_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert len(declared) >= 40
+    import ctypes
+    for name in declared:
+        assert hasattr(mqlib, name), "libmqhip.so does not export %s" % name
+    assert declared == set(mqlib._mq_symbols), declared ^ set(mqlib._mq_symbols)
+    assert mqlib.mq_abi_version() == 1
+    assert ctypes.sizeof(mq.Uniform) == 124  # res/shader/scene_info.glsl.h:18-32
+    assert mq.EXT_DTYPE.itemsize == 28       # src/game/quake_helpers.hpp:10-34
+
+
+def test_host_only_context_refuses_device_work(mq):
+    ctx = mq.Context(-1)
+    ctx.synth_scene("synth_tiny", 1)
+    ctx.commit()  # BVH build is host work
+    assert ctx.scene_stats()["n_tris"] > 500
+    for call in (lambda: ctx.connect(64, 48), lambda: ctx.process(ctx.synth_camera(0)), lambda: ctx.sync(),
+                 lambda: ctx.trace_rays(np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32)),
+                 lambda: ctx.math_eval(0, np.zeros((1, 1), np.float32), 1), lambda: ctx.last_frame_ms(), lambda: ctx.counters()):
+        with pytest.raises(mq.MqError) as e:
+            call()
+        assert e.value.code == mq.MQ_ENODEVICE
+    with pytest.raises(mq.MqError):
+        mq.Context(99)  # no such device
+
+
+# property keys and shipped values transcribed from res/default_config.json:599-638 (render_markovchain) and :527-535 (gbuffer)
+REFERENCE_JSON = {"graph": {"nodes": {
+    "gbuffer": {"disable": False, "properties": {"enable albedo mipmap": True, "enable emission mipmap": True, "hide sun": True}, "type": "GBuffer"},
+    "render_markovchain": {"disable": False, "properties": {
+        "BSDF Prob": 0.10000000149011612, "LC buf size": 4000037, "LC grid min width": 0.009999999776482582, "LC grid power": 2.0,
+        "LC grid steps per unit": 6.0, "LC grid tan(alpha/2)": 0.004999999888241291, "LC grid type": "quadratic", "ML Prior": 0.30000001192092896,
+        "Phase Prob": 0.10000000149011612, "adaptive grid buf size": 32777259, "adaptive grid min width": 0.009999999776482582,
+        "adaptive grid power": 1.7320507764816284, "adaptive grid prob": 0.699999988079071, "adaptive grid steps per unit": 1.0,
+        "adaptive grid tan(alpha/2)": 0.0020000000949949026, "adaptive grid type": "exponential", "debug output": "light cache",
+        "dist guide p": 0.8999999761581421, "dist mc grid width": 25, "dist mc samples": 3, "dist mc states per vertex": 10,
+        "max path length": 3, "mc fast recovery": True, "mc samples": 5, "mc static width": 25.299999237060547, "particle size": 7.0,
+        "randomize seed": True, "reference mode": False, "spp": 2, "static grid buf size": 800009, "surf: use LC": False,
+        "volume forward project": True, "volume spp": 2, "volume: use LC": True}, "type": "Renderer (MCPG)"}}}}
+
+
+def test_property_table_uses_reference_keys_and_defaults(mq):
+    ctx = mq.Context(-1)
+    names = ctx.property_names()
+    ref_keys = set(REFERENCE_JSON["graph"]["nodes"]["render_markovchain"]["properties"]) | set(REFERENCE_JSON["graph"]["nodes"]["gbuffer"]["properties"])
+    assert ref_keys <= set(names), ref_keys - set(names)
+    # header defaults: src/render_mcpg/render_mcpg.hpp:108-166
+    hdr = {"spp": 1, "volume spp": 0, "max path length": 3, "BSDF Prob": 0.15, "Phase Prob": 0.3, "ML Prior": 0.2, "dist guide p": 0.0,
+           "mc samples": 5, "adaptive grid prob": 0.7, "adaptive grid tan(alpha/2)": 0.003, "adaptive grid power": 4.0,
+           "adaptive grid steps per unit": 6.0, "static grid buf size": 800009, "mc static width": 25.3, "LC buf size": 4000000,
+           "LC grid type": 0, "randomize seed": 1, "mc fast recovery": 1, "adaptive grid buf size": 32777259, "hide sun": 1}
+    for k, v in hdr.items():
+        assert ctx.get_property(k) == pytest.approx(v, rel=1e-6), k
+    # json_defaults() == loading the reference's shipped JSON
+    a = mq.Context(-1); a.json_defaults()
+    b = mq.Context(-1)
+    txt = json.dumps(REFERENCE_JSON)
+    assert b.load_properties_json(txt, "render_markovchain") == 1  # NEEDS_RECONNECT: LC grid type / sizes changed
+    b.load_properties_json(txt, "gbuffer")
+    for k in names:
+        assert a.get_property(k) == b.get_property(k), k
+    assert b.get_property("LC grid type") == 1 and b.get_property("spp") == 2 and b.get_property("volume: use LC") == 1
+    # option by string, unknown key, out-of-range values
+    assert ctx.set_property("LC grid type", "quadratic") == 1      # reconnect class (render_mcpg.cpp:567-575)
+    assert ctx.set_property("BSDF Prob", 0.25) == 0                # pipeline-refresh class
+    assert ctx.set_property("BSDF Prob", 0.25) == 0
+    with pytest.raises(mq.MqError):
+        ctx.set_property("no such key", 1)
+    with pytest.raises(mq.MqError):
+        ctx.set_property("LC grid type", "cubic")
+    with pytest.raises(mq.MqError):
+        ctx.set_property("mc samples", 31)
+
+
+def test_describe_matches_reference_buffer_sizes(mq):
+    ctx = mq.Context(-1)
+    d = ctx.describe(1920, 1080)
+    px = 1920 * 1080
+    assert d.bytes[mq.OUT_IRRADIANCE] == px * 16       # RGBA32F, render_mcpg.cpp:42-43
+    assert d.bytes[mq.OUT_HITS] == px * 40             # CompressedHit, gbuffer.cpp:39
+    assert d.bytes[mq.OUT_GB_ALBEDO] == px * 8 and d.bytes[mq.OUT_GB_MV] == px * 4
+    assert d.state_bytes_lightcache == 4000000 * 16
+    assert d.state_bytes_markovchain == (32777259 + 800009) * (64 + 8)  # render_mcpg.cpp:59 slots, 64 B states + 2 queue words
+
+
+def test_synthetic_scenes_are_deterministic_and_well_formed(mq):
+    a, b = mq.Context(-1), mq.Context(-1)
+    a.synth_scene("synth_start", 5); b.synth_scene("synth_start", 5)
+    ga, gb = a.get_geometry(0), b.get_geometry(0)
+    assert np.array_equal(ga["vtx"], gb["vtx"]) and np.array_equal(ga["idx"], gb["idx"]) and np.array_equal(ga["ext"], gb["ext"])
+    c = mq.Context(-1); c.synth_scene("synth_start", 6)
+    assert not np.array_equal(c.get_geometry(0)["ext"], ga["ext"])
+    assert 25000 < len(ga["idx"]) < 45000  # stand-in for id1 start.bsp, SURVEY 8d
+    assert ga["flags"] & mq.MQ_GEO_OPAQUE
+    # every triangle is non-degenerate and its reference normal cross(v2-v0, v1-v0) is axis aligned or a pillar side
+    tri = ga["vtx"][ga["idx"]].astype(np.float64)
+    nrm = np.cross(tri[:, 2] - tri[:, 0], tri[:, 1] - tri[:, 0])
+    assert (np.linalg.norm(nrm, axis=1) > 1e-3).all()
+    # emissive (fullbright) tiles exist and are a few percent; sky brushes only in outdoor scenes
+    fb = ga["ext"]["texnum_fb_flags"]
+    assert 0.005 < ((fb & 0xFFF) > 0).mean() < 0.1
+    assert ((fb >> 12) == 5).sum() == 0
+    d = mq.Context(-1); d.synth_scene("synth_tiny", 1)
+    assert ((d.get_geometry(0)["ext"]["texnum_fb_flags"] >> 12) == 5).sum() > 0
+    # alpha-tested slot uses texture alpha (nibble 0) and is not flagged opaque; dynamic slot has prev_vtx != vtx
+    g1 = a.get_geometry(1)
+    if g1 is not None:
+        assert (g1["ext"]["texnum_alpha"] >> 12 == 0).all() and not (g1["flags"] & mq.MQ_GEO_OPAQUE)
+    g2 = a.get_geometry(2)
+    assert g2 is not None and not np.array_equal(g2["vtx"], g2["prev_vtx"])
+    u0, u1 = a.synth_camera(0), a.synth_camera(1)
+    assert list(u1.prev_cam_x)[:3] == list(u0.cam_x)[:3]
+    assert abs(np.linalg.norm(list(u0.cam_w)[:3]) - 1) < 1e-5 and abs(np.dot(list(u0.cam_w)[:3], list(u0.cam_u)[:3])) < 1e-5
+    with pytest.raises(mq.MqError):
+        a.synth_scene("no_such_scene", 1)
+
+
+def _decode_children(node):
+    e = (node["e"].astype(np.uint32) << 23).view(np.float32)
+    lo = node["p"][:, None] + node["qlo"].astype(np.float32) * e[:, None]
+    hi = node["p"][:, None] + node["qhi"].astype(np.float32) * e[:, None]
+    return lo, hi
+
+
+def test_cwbvh_invariants(mq):
+    ctx = mq.Context(-1)
+    ctx.synth_scene("synth_tiny", 2)
+    ctx.commit()
+    nodes, tris = ctx.get_bvh()
+    total = sum(len(ctx.get_geometry(s)["idx"]) for s in range(3) if ctx.get_geometry(s) is not None)
+    assert len(tris) == total
+    assert len(np.unique(tris["key"])) == total  # every triangle exactly once
+    seen_nodes = np.zeros(len(nodes), bool)
+    seen_tris = np.zeros(len(tris), bool)
+    stack = [(0, None, None)]
+    while stack:
+        ni, plo, phi = stack.pop()
+        assert not seen_nodes[ni]
+        seen_nodes[ni] = True
+        node = nodes[ni]
+        lo, hi = _decode_children(node)
+        child = int(node["child_base"])
+        for s in range(8):
+            m = int(node["meta"][s])
+            if m == 0:
+                assert node["qlo"][0][s] > node["qhi"][0][s]  # empty slots can never be hit
+                continue
+            clo, chi = lo[:, s], hi[:, s]
+            if plo is not None:  # child box inside the parent's decoded box
+                assert (clo >= plo - 1e-3).all() and (chi <= phi + 1e-3).all()
+            if (m & 0x18) == 0x18:  # internal: low 5 bits = 24 + slot, imask bit set, children contiguous in slot order
+                assert (m & 31) == 24 + s and (m >> 5) == 1 and (int(node["imask"]) >> s) & 1
+                stack.append((child, clo, chi)); child += 1
+            else:
+                cnt = {1: 1, 3: 2, 7: 3}[m >> 5]
+                first = int(node["tri_base"]) + (m & 31)
+                for t in range(first, first + cnt):
+                    assert not seen_tris[t]
+                    seen_tris[t] = True
+                    v = tris[t]["v"]
+                    assert (v.min(0) >= clo).all() and (v.max(0) <= chi).all()  # conservative quantised boxes
+    assert seen_nodes.all() and seen_tris.all()
+    st = ctx.scene_stats()
+    assert st["bvh_bytes"] == len(nodes) * 80 + len(tris) * 48
+
+
+def _write_bsp(path, bsp2):
+    """A one-room box map: 6 quad faces, two textures (a wall with fullbright texels, a sky), worldspawn sun keys."""
+    verts = np.array([[x, y, z] for z in (0, 128) for y in (0, 256) for x in (0, 256)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    edges = [(0, 0)]
+    surfedges = []
+    faces = []
+    for qi, q in enumerate(quads):
+        first = len(surfedges)
+        for k in range(4):
+            edges.append((q[k], q[(k + 1) % 4])); surfedges.append(len(edges) - 1)
+        faces.append((first, 4, 1 if qi == 1 else 0))
+    def miptex(name, w, h, px):
+        off = 40
+        return struct.pack("<16sII4I", name, w, h, off, 0, 0, 0) + bytes(px)
+    wall = [100] * (16 * 16); wall[5] = 250; wall[6] = 251  # two fullbright texels (palette index >= 224)
+    sky = [7] * (32 * 16)
+    mips = [miptex(b"wall1", 16, 16, wall), miptex(b"sky1", 32, 16, sky)]
+    ofs = 4 + 4 * len(mips)
+    lump_tex = struct.pack("<i", len(mips))
+    acc = b""
+    for m in mips:
+        lump_tex += struct.pack("<i", ofs + len(acc)); acc += m
+    lump_tex += acc
+    texinfo = b"".join(struct.pack("<8fii", 1, 0, 0, 0, 0, 1, 0, 0, i, 0) for i in range(2))
+    if bsp2:
+        lump_faces = b"".join(struct.pack("<iiiii4Bi", 0, 0, f[0], f[1], f[2], 0, 0, 0, 0, -1) for f in faces)
+        lump_edges = b"".join(struct.pack("<II", *e) for e in edges)
+    else:
+        lump_faces = b"".join(struct.pack("<hhihh4Bi", 0, 0, f[0], f[1], f[2], 0, 0, 0, 0, -1) for f in faces)
+        lump_edges = b"".join(struct.pack("<HH", *e) for e in edges)
+    ents = b'{\n"classname" "worldspawn"\n"_sunlight" "8000"\n"_sunlight_color" "1 0.5 0.25"\n"_sun_mangle" "90 -45 0"\n}\n{\n"classname" "info_player_start"\n"origin" "128 128 24"\n"angle" "90"\n}\n\x00'
+    model = struct.pack("<9f4iiii", 0, 0, 0, 256, 256, 128, 0, 0, 0, 0, 0, 0, 0, 0, 0, len(faces))
+    lumps = [ents, b"", lump_tex, verts.tobytes(), b"", b"", texinfo, lump_faces, b"", b"", b"", b"", lump_edges,
+             struct.pack("<%di" % len(surfedges), *surfedges), model]
+    hdr_len = 4 + 15 * 8
+    body = b""; table = b""
+    for l in lumps:
+        table += struct.pack("<ii", hdr_len + len(body), len(l)); body += l + b"\x00" * ((-len(l)) % 4)
+    with open(path, "wb") as f:
+        f.write((b"BSP2" if bsp2 else struct.pack("<i", 29)) + table + body)
+
+
+@pytest.mark.parametrize("bsp2", [False, True])
+def test_bsp_loader(mq, tmp_path, bsp2):
+    path = str(tmp_path / ("box2.bsp" if bsp2 else "box29.bsp"))
+    _write_bsp(path, bsp2)
+    ctx = mq.Context(-1)
+    ctx.load_bsp(path)
+    g = ctx.get_geometry(0)
+    assert len(g["idx"]) == 12 and len(g["vtx"]) == 24          # 6 quads -> fan triangles (quake_helpers.cpp:419-423)
+    assert np.array_equal(g["idx"][:2], [[0, 1, 2], [0, 2, 3]])
+    flags = g["ext"]["texnum_fb_flags"] >> 12
+    assert (flags == 5).sum() == 2                                # the sky face carries MAT_FLAGS_SKY
+    assert (g["ext"]["n1_brush"] == 0xFFFFFFFF).all()
+    wall = g["ext"][flags == 0]
+    assert (wall["texnum_alpha"] >> 12 == 15).all() and ((wall["texnum_fb_flags"] & 0xFFF) > 0).all()  # opaque + fullbright mask
+    fb_px, _ = ctx.get_texture(int(wall["texnum_fb_flags"][0] & 0xFFF))
+    assert (fb_px[..., :3].reshape(-1, 3).sum(1) > 0).sum() == 2  # only the two fullbright texels survive in the mask
+    c = ctx.get_constants()
+    assert c["sun_color"] == pytest.approx([2.0, 1.0, 0.5])       # 8000/4000 * colour (quake_node.cpp:266-283)
+    assert abs(np.linalg.norm(c["sun_direction"]) - 1) < 1e-6
+    u = ctx.synth_camera(0)
+    assert abs(u.cam_x[2] - 46.0) < 1e-3                          # origin z + 22 eye height
+    assert (u.sky_lf_ft & 0xFFFF) == 0xFFFF                       # classic sky marker (raytrace.glsl:35)
+    ctx.commit()
+    assert ctx.scene_stats()["n_tris"] == 12
+    with pytest.raises(mq.MqError):
+        ctx.load_bsp(str(tmp_path / "missing.bsp"))
+    bad = tmp_path / "bad.bsp"
+    bad.write_bytes(struct.pack("<i", 30) + b"\x00" * 200)
+    with pytest.raises(mq.MqError):
+        ctx.load_bsp(str(bad))
+
+
+def test_scene_upload_validation(mq):
+    ctx = mq.Context(-1)
+    vtx = np.zeros((3, 3), np.float32)
+    ext = np.zeros(1, mq.EXT_DTYPE)
+    with pytest.raises(mq.MqError):
+        ctx.set_geometry(0, vtx, None, np.array([[0, 1, 3]], np.uint32), ext, 0)  # index out of range
+    with pytest.raises(mq.MqError):
+        ctx.set_geometry(16, vtx, None, np.array([[0, 1, 2]], np.uint32), ext, 0)  # MAX_GEOMETRIES (config.h:6)
+    with pytest.raises(mq.MqError):
+        ctx.set_texture(4096, np.zeros((2, 2, 4), np.uint8), 0)                     # MAX_GLTEXTURES (config.h:5)
+    ctx.commit()  # an empty scene commits (everything misses -> sky)
+    assert ctx.scene_stats()["n_tris"] == 0
