@@ -7,6 +7,7 @@ the HIP extension cannot be loaded, import fails loudly.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -68,6 +69,14 @@ def load_library(path=None):
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise ImportError("libmqhip.so not built (%s): run __graft_entry__.build() or `make -C merian-quake_amd`" % path)
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  A process must end up with
+    # ONE HIP/HSA runtime, so when torch is part of the process (bench.py: RCCL via torch.distributed)
+    # it has to be loaded first; libmqhip then binds to the already-loaded runtime.
+    if "torch" not in sys.modules and os.environ.get("MQHIP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(path)
     P, u32, i32, f32p, u32p, vp, sz = C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t
     sigs = {

@@ -1,0 +1,50 @@
+// Host-only exercise of include/mq_node.hpp: lifecycle order, property visitor (a JSON-load style
+// visitor that overrides some values), NEEDS_RECONNECT, and the loud failure without a HIP device.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include "mq_node.hpp"
+
+struct Loader : mq::Properties { // behaves like merian's JSONLoadProperties: overrides what it knows
+    std::map<std::string, double> vals; std::map<std::string, std::string> opts; int visited = 0;
+    bool config_bool(const std::string& id, bool& v) override { visited++; auto it = vals.find(id); if (it == vals.end()) return false; v = it->second != 0; return true; }
+    bool config_int(const std::string& id, int32_t& v) override { visited++; auto it = vals.find(id); if (it == vals.end()) return false; v = (int32_t)it->second; return true; }
+    bool config_uint(const std::string& id, uint32_t& v) override { visited++; auto it = vals.find(id); if (it == vals.end()) return false; v = (uint32_t)it->second; return true; }
+    bool config_float(const std::string& id, float& v) override { visited++; auto it = vals.find(id); if (it == vals.end()) return false; v = (float)it->second; return true; }
+    bool config_options(const std::string& id, int& sel, const std::vector<std::string>& o) override {
+        visited++; auto it = opts.find(id); if (it == opts.end()) return false;
+        for (size_t i = 0; i < o.size(); i++) if (o[i] == it->second) { sel = (int)i; return true; }
+        return false;
+    }
+};
+#define REQUIRE(c) do { if (!(c)) { printf("FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main() {
+    mq::RendererMarkovChainHIP node(-1); // host-only: properties, describe, scene; no device
+    REQUIRE(node.describe_inputs().size() == 8);
+    auto outs = node.describe_outputs(1920, 1080);
+    REQUIRE(outs[0].name == "irradiance" && outs[0].bytes == 1920u * 1080u * 16u);
+    REQUIRE(outs[5].name == "hits" && outs[5].bytes == 1920u * 1080u * 40u);
+    Loader l;
+    l.vals["spp"] = 2; l.vals["BSDF Prob"] = 0.1; l.vals["reference mode"] = 0; l.vals["seed"] = 1234; l.vals["randomize seed"] = 0;
+    REQUIRE(node.properties(l) == mq::NONE);          // only pipeline-refresh class changes
+    REQUIRE(l.visited == mq_property_count());
+    double v = 0; mq_get_property(node.handle(), "spp", &v); REQUIRE(v == 2);
+    mq_get_property(node.handle(), "BSDF Prob", &v); REQUIRE(v > 0.0999 && v < 0.1001);
+    Loader l2; l2.opts["LC grid type"] = "quadratic"; l2.vals["LC buf size"] = 4000037;
+    REQUIRE(node.properties(l2) == mq::NEEDS_RECONNECT);  // render_mcpg.cpp:567-575
+    REQUIRE(node.properties(l2) == mq::NONE);              // idempotent
+    // a tiny scene can be handed over and committed on the host ...
+    float vtx[9] = {0, 0, 0, 1, 0, 0, 0, 1, 0}; uint32_t idx[3] = {0, 2, 1}; mq_ext ext; memset(&ext, 0, sizeof ext);
+    node.set_geometry(0, vtx, nullptr, 3, idx, &ext, 1, MQ_GEO_OPAQUE);
+    // ... but connecting / processing without a HIP device fails loudly (no CPU fallback)
+    bool threw = false;
+    try { node.on_connected(); } catch (const mq::Error& e) { threw = e.code == MQ_ENODEVICE; }
+    REQUIRE(threw);
+    threw = false;
+    mq::RenderInfo info;
+    try { node.process(info, nullptr); } catch (const mq::Error& e) { threw = e.code == MQ_ENODEVICE; }
+    REQUIRE(threw);
+    printf("node adapter ok\n");
+    return 0;
+}

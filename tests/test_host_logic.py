@@ -273,3 +273,14 @@ def test_scene_upload_validation(mq):
         ctx.set_texture(4096, np.zeros((2, 2, 4), np.uint8), 0)                     # MAX_GLTEXTURES (config.h:5)
     ctx.commit()  # an empty scene commits (everything misses -> sky)
     assert ctx.scene_stats()["n_tris"] == 0
+
+
+def test_cpp_node_adapter(built, tmp_path):
+    """include/mq_node.hpp (the merian-style five-method adapter) compiles against mq.h alone and behaves."""
+    import subprocess
+    exe = str(tmp_path / "node_adapter_test")
+    libdir = os.path.join(ROOT, "merian-quake_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "node_adapter_test.cpp"),
+                    "-L" + libdir, "-lmqhip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0 and "node adapter ok" in r.stdout, r.stdout
