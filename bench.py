@@ -155,14 +155,33 @@ def main():
     c = ctx.counters()
     ctx.enable_counters(False)
     local_pixels = c["pixels"]
+    det = ctx.timing_detail()
+    kms = {"mq_primary_kernel": det["primary_ms"] / n_timed, "mq_trace_queue_kernel": det["trace_ms"] / n_timed,
+           "mq_bounce_kernel": det["bounce_ms"] / n_timed, "mq_apply_kernel": update_sum / n_timed}
+    rounds = args.spp * 2  # spp * (max path length - 1) launches of trace + bounce per frame
+    # algorithmic bytes per kernel class (SURVEY.md 8d prices)
+    prim_rays = c["rays"] - c["queue_rays"]
+    kbytes = {
+        "mq_primary_kernel": local_pixels * 56 + 80 * (c["nodes"] - c["queue_nodes"]) + 48 * (c["tris"] - c["queue_tris"]) + 120 * prim_rays,
+        "mq_trace_queue_kernel": 80 * c["queue_nodes"] + 48 * c["queue_tris"] + 48 * c["queue_rays"],   # + 32 B ray in, 16 B hit out
+        "mq_bounce_kernel": c["queue_rays"] * (120 + 16 + 4 + 320) + 64 * c["mc_state_reads"] + 24 * c["lc_touches"] + 64 * c["mc_updates_accepted"],
+        "mq_apply_kernel": 128 * c["mc_updates_accepted"],
+    }
     B = algorithmic_bytes(c, local_pixels)
-    avg_render_ms = render_sum / n_timed
-    achieved = B / (avg_render_ms * 1e-3) / 1e9
+    dom = max(("mq_trace_queue_kernel", "mq_bounce_kernel", "mq_primary_kernel"), key=lambda k: kms[k])
+    launches = {"mq_primary_kernel": 1, "mq_trace_queue_kernel": rounds, "mq_bounce_kernel": rounds, "mq_apply_kernel": 1}
+    dom_ms_per_launch = kms[dom] / launches[dom]
+    dom_bytes_per_launch = kbytes[dom] / launches[dom]
+    achieved = dom_bytes_per_launch / (dom_ms_per_launch * 1e-3) / 1e9
+    pipeline_ms = render_sum / n_timed
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "mq_render_kernel<guided>" if not args.reference_mode else "mq_render_kernel<reference>",
-                "kernel_ms": round(avg_render_ms, 4), "update_kernel_ms": round(update_sum / n_timed, 4), "algorithmic_bytes_per_launch": int(B),
-                "bytes_per_sample": round(B / max(1, local_pixels * args.spp), 1), "counters": c}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom,
+                "kernel_ms_per_launch": round(dom_ms_per_launch, 4), "launches_per_frame": launches[dom],
+                "algorithmic_bytes_per_launch": int(dom_bytes_per_launch),
+                "frame": {"algorithmic_bytes": int(B), "render_ms": round(pipeline_ms, 4), "achieved": round(B / (pipeline_ms * 1e-3) / 1e9, 1),
+                          "frac": round(B / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": round(B / max(1, local_pixels * args.spp), 1)},
+                "kernels_ms_per_frame": {k: round(v, 4) for k, v in kms.items()},
+                "kernels_algorithmic_bytes_per_frame": {k: int(v) for k, v in kbytes.items()}, "counters": c}
 
     out = {"metric": "Msamples/s at 1920x1080 1spp (ad_sepulcher); per-pixel L2 vs reference", "value": round(value, 3),
            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

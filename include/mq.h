@@ -104,6 +104,7 @@ typedef struct mq_io_desc {
 typedef struct mq_counters {
     uint64_t rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels;
+    uint64_t queue_rays, queue_nodes, queue_tris; /* the bounce-ray traversal kernel alone */
 } mq_counters;
 
 typedef struct mq_ctx mq_ctx;
@@ -172,6 +173,8 @@ int mq_last_frame_ms(mq_ctx* ctx, float* total_ms, float* render_ms, float* upda
  * render_mcpg.cpp:255 */
 int mq_timing_reset(mq_ctx* ctx);
 int mq_timing_get(mq_ctx* ctx, uint32_t* frames, double* render_ms_sum, double* update_ms_sum);
+/* the render time split by kernel class: primary (first hit), trace (BVH traversal of bounce rays), bounce (shading/guiding) */
+int mq_timing_get_detail(mq_ctx* ctx, double* primary_ms_sum, double* trace_ms_sum, double* bounce_ms_sum);
 /* enable work counting for subsequent frames (separate kernel instantiation, slower) */
 int mq_enable_counters(mq_ctx* ctx, int on);
 int mq_get_counters(mq_ctx* ctx, mq_counters* out);

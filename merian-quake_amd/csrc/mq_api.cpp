@@ -21,7 +21,9 @@
 #include "mq_host.h"
 
 // launchers implemented in mq_kernels.hip
-int mq_launch_render(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s);
+int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s);
+int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s);
+int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s);
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
@@ -29,7 +31,6 @@ int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, ui
 int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int no, const float* in, float* out, uint32_t n, hipStream_t s);
 int mq_render_block_size();
 int mq_spill_entries();
-int mq_render_blocks_per_cu(bool guided, bool count);
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -59,6 +60,7 @@ struct mq_ctx {
     uint32_t n_local_tiles = 0, tiles_per_rank = 0;
     DevBuf d_out[MQ_OUT_COUNT];
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
+    DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2];
     uint32_t queue_cap = 0;
     uint32_t mc_total = 0, lc_total = 0;
     uint64_t iteration = 0;
@@ -66,8 +68,11 @@ struct mq_ctx {
     MqParams params{};
     bool count_enabled = false;
     int cu_count = 0, grid_blocks = 0;
-    static const int EV_RING = 64;
-    hipEvent_t evr[EV_RING][3] = {};
+    static const int EV_RING = 32;
+    static const int EV_PER = 3 + 2 * 8; // start, primary end, (trace end, bounce end) x up to 8 rounds, apply end
+    hipEvent_t evr[EV_RING][EV_PER] = {};
+    int ev_rounds[EV_RING] = {};
+    double t_primary_sum = 0.0, t_trace_sum = 0.0, t_bounce_sum = 0.0;
     bool ev_pending[EV_RING] = {};
     int ev_slot = 0, ev_last = -1;
     double t_render_sum = 0.0, t_update_sum = 0.0; uint32_t t_frames = 0;
@@ -264,6 +269,7 @@ void free_frame_state(mq_ctx* c) {
     for (auto& b : c->d_out) dev_free(b);
     dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
+    dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
 void free_scene_dev(mq_ctx* c) {
@@ -577,24 +583,35 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     size_t segs = (size_t)c->tiles_per_rank * 64 * (size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1);
     c->queue_cap = (uint32_t)std::min<size_t>(segs, 0x7fffffffu);
     if ((r = dev_alloc(c, c->d_queue, (size_t)c->queue_cap * sizeof(MqUpdate)))) return r;
-    if ((r = dev_alloc(c, c->d_ctrl, 64))) return r;
+    if ((r = dev_alloc(c, c->d_ctrl, MQ_CTRL_WORDS * 4))) return r;
     if ((r = dev_alloc(c, c->d_counters, sizeof(MqCountersDev)))) return r;
     HIPCHK(c, hipMemset(c->d_counters.p, 0, sizeof(MqCountersDev)));
-    int per_cu = std::max(1, mq_render_blocks_per_cu(true, true));
-    c->grid_blocks = std::max(1, c->cu_count) * std::min(per_cu, 8);
+    c->grid_blocks = std::max(1, c->cu_count) * 8;
     if ((r = dev_alloc(c, c->d_spill, (size_t)c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
+    const size_t slots = (size_t)c->tiles_per_rank * 64;
+    if ((r = dev_alloc(c, c->d_paths, slots * 160))) return r;
+    if ((r = dev_alloc(c, c->d_rays, slots * 32))) return r;
+    if ((r = dev_alloc(c, c->d_ray_hits, slots * 16))) return r;
+    if ((r = dev_alloc(c, c->d_qslots[0], slots * 4))) return r;
+    if ((r = dev_alloc(c, c->d_qslots[1], slots * 4))) return r;
     c->iteration = 0; c->connected = true; c->params_dirty = true;
     return MQ_OK;
 }
 
 static int drain_slot(mq_ctx* c, int slot) {
     if (!c->ev_pending[slot]) return MQ_OK;
-    HIPCHK(c, hipEventSynchronize(c->evr[slot][2]));
-    float a = 0, b = 0;
-    HIPCHK(c, hipEventElapsedTime(&a, c->evr[slot][0], c->evr[slot][1]));
-    HIPCHK(c, hipEventElapsedTime(&b, c->evr[slot][1], c->evr[slot][2]));
-    c->t_render_sum += a; c->t_update_sum += b; c->t_frames++;
-    if (slot == c->ev_last) { c->last_render_ms = a; c->last_update_ms = b; }
+    const int R = c->ev_rounds[slot], last = 2 + 2 * R;
+    HIPCHK(c, hipEventSynchronize(c->evr[slot][last]));
+    float prim = 0, tr = 0, bo = 0, ap = 0, x = 0;
+    HIPCHK(c, hipEventElapsedTime(&prim, c->evr[slot][0], c->evr[slot][1]));
+    for (int k = 0; k < R; k++) {
+        HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][1 + 2 * k], c->evr[slot][2 + 2 * k])); tr += x;
+        HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][2 + 2 * k], c->evr[slot][3 + 2 * k])); bo += x;
+    }
+    HIPCHK(c, hipEventElapsedTime(&ap, c->evr[slot][1 + 2 * R], c->evr[slot][last]));
+    c->t_primary_sum += prim; c->t_trace_sum += tr; c->t_bounce_sum += bo;
+    c->t_render_sum += prim + tr + bo; c->t_update_sum += ap; c->t_frames++;
+    if (slot == c->ev_last) { c->last_render_ms = prim + tr + bo; c->last_update_ms = ap; }
     c->ev_pending[slot] = false;
     return MQ_OK;
 }
@@ -611,6 +628,8 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
     F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.counters = (MqCountersDev*)c->d_counters.p;
     F.stack_spill = (unsigned long long*)c->d_spill.p;
+    F.paths = (uint4*)c->d_paths.p; F.rays = (float4*)c->d_rays.p; F.ray_hits = (uint4*)c->d_ray_hits.p;
+    F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p;
 }
 
 int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
@@ -635,20 +654,34 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
         return MQ_OK;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, 64, s));
+    HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, MQ_CTRL_WORDS * 4, s));
     if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(MqCountersDev), s));
     const bool guided = !c->params.reference_mode;
+    // rounds: every sample needs at most (max_path_length - 1) traced segments, render_mcpg.cpp:142-143
+    const int rounds = std::max(0, c->params.spp) * std::max(0, c->params.max_path_length - 1);
+    if (rounds > MQ_MAX_ROUNDS) return fail(c, MQ_EINVAL, "spp * (max path length - 1) exceeds the round limit of this build");
+    const int timed = std::min(rounds, 8); // rounds beyond the 8th are not split out (their time lands in the update interval)
     const int slot = c->ev_slot;
     { int r = drain_slot(c, slot); if (r) return r; } // the slot's previous frame finished long ago
-    HIPCHK(c, hipEventRecord(c->evr[slot][0], s));
-    int e = mq_launch_render(c->scene, c->params, F, guided, c->count_enabled, c->grid_blocks, s);
-    if (e) return fail(c, MQ_EHIP, std::string("render launch: ") + hipGetErrorString((hipError_t)e));
-    HIPCHK(c, hipEventRecord(c->evr[slot][1], s));
+    hipEvent_t* ev = c->evr[slot];
+    HIPCHK(c, hipEventRecord(ev[0], s));
+    int e = mq_launch_primary(c->scene, c->params, F, guided, c->count_enabled, c->grid_blocks, s);
+    if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
+    HIPCHK(c, hipEventRecord(ev[1], s));
+    for (int r = 0; r < rounds; r++) {
+        e = mq_launch_trace_queue(c->scene, F, r, c->count_enabled, c->grid_blocks, s);
+        if (e) return fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e));
+        if (r < timed) HIPCHK(c, hipEventRecord(ev[2 + 2 * r], s));
+        e = mq_launch_bounce(c->scene, c->params, F, r, guided, c->count_enabled, c->grid_blocks, s);
+        if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
+        if (r < timed) HIPCHK(c, hipEventRecord(ev[3 + 2 * r], s));
+    }
     if (guided) { // render_mcpg.cpp:261-277
         e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, s);
         if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     }
-    HIPCHK(c, hipEventRecord(c->evr[slot][2], s));
+    HIPCHK(c, hipEventRecord(ev[2 + 2 * timed], s));
+    c->ev_rounds[slot] = timed;
     c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
     c->ev_valid = true;
     return MQ_OK;
@@ -690,6 +723,7 @@ int mq_timing_reset(mq_ctx* c) {
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
     for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
     c->t_render_sum = c->t_update_sum = 0.0; c->t_frames = 0;
+    c->t_primary_sum = c->t_trace_sum = c->t_bounce_sum = 0.0;
     return MQ_OK;
 }
 int mq_timing_get(mq_ctx* c, uint32_t* frames, double* render_ms_sum, double* update_ms_sum) {
@@ -697,6 +731,13 @@ int mq_timing_get(mq_ctx* c, uint32_t* frames, double* render_ms_sum, double* up
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
     for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
     if (frames) *frames = c->t_frames; if (render_ms_sum) *render_ms_sum = c->t_render_sum; if (update_ms_sum) *update_ms_sum = c->t_update_sum;
+    return MQ_OK;
+}
+int mq_timing_get_detail(mq_ctx* c, double* primary_ms_sum, double* trace_ms_sum, double* bounce_ms_sum) {
+    if (!c) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
+    if (primary_ms_sum) *primary_ms_sum = c->t_primary_sum; if (trace_ms_sum) *trace_ms_sum = c->t_trace_sum; if (bounce_ms_sum) *bounce_ms_sum = c->t_bounce_sum;
     return MQ_OK;
 }
 int mq_enable_counters(mq_ctx* c, int on) { if (!c) return MQ_EINVAL; c->count_enabled = on != 0; return MQ_OK; }
@@ -711,6 +752,7 @@ int mq_get_counters(mq_ctx* c, mq_counters* out) {
     out->rays = d.rays; out->nodes = d.nodes; out->tris = d.tris; out->segments = d.segments; out->guided_segments = d.guided_segments;
     out->lc_touches = d.lc_touches; out->mc_updates_accepted = d.mc_updates_accepted; out->mc_updates_dropped = d.mc_updates_dropped;
     out->mc_state_reads = d.mc_state_reads; out->pixels = d.pixels;
+    out->queue_rays = d.q_rays; out->queue_nodes = d.q_nodes; out->queue_tris = d.q_tris;
     return MQ_OK;
 }
 

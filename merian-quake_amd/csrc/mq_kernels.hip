@@ -1,8 +1,9 @@
 // mq_kernels.hip -- hand-written gfx950 kernels of the MCPG path tracer.
 //
-//   mq_render_kernel     persistent-wavefront megakernel: primary ray (g-buffer node,
-//                        res/shader/gbuffer/gbuffer.comp:75-131) + surface estimator
-//                        (res/shader/render_mcpg/mcpg.comp:39-210) over a software CWBVH.
+//   mq_primary_kernel    primary ray + g-buffer node (res/shader/gbuffer/gbuffer.comp:75-131) and the
+//                        first direction choice of the surface estimator
+//   mq_trace_queue_kernel software CWBVH closest hit for every queued ray
+//   mq_bounce_kernel     shading + guiding + learning of res/shader/render_mcpg/mcpg.comp:39-210
 //   mq_apply_kernel      Markov-chain update application (compute_updates.comp:56-124) over a
 //                        compact update queue instead of the reference's 17 GB slot array.
 //   mq_clear_kernel      clear.comp:15-23 + the CLEAR variant of gbuffer.comp:83-90.
@@ -10,17 +11,23 @@
 //   mq_trace_kernel      closest-hit queries (raytrace.glsl:82-119 semantics).
 //   mq_math_kernel       device-side known-answer evaluation of the shading primitives.
 //
-// Scheduling: one path per lane.  A wave pulls pixels from a global counter with one aggregated
-// atomic per refill (ballot + mbcnt), so lanes whose path ended are re-armed immediately and the
-// single traversal call site always sees the maximum number of live rays (primary and bounce rays
-// share it).  Traversal stacks live in LDS ([entry][lane] layout, conflict free) with a global
-// spill area behind them.  No MFMA: the path is divergent traversal, not a contraction.
+// Scheduling: a wavefront pipeline with stream compaction between rounds (see the block comment
+// above mq_primary_kernel).  Traversal stacks live in LDS ([entry][lane] layout, conflict free)
+// with a global spill area behind them.  No MFMA: the path is divergent traversal, not a contraction.
 #include "mq_device.h"
 
 #define MQ_BLOCK 256
 #define MQ_WAVES (MQ_BLOCK / 64)
+#ifndef MQ_STACK_LDS
 #define MQ_STACK_LDS 12
-#define MQ_SPILL_ENTRIES 52
+#endif
+#define MQ_SPILL_ENTRIES (64 - MQ_STACK_LDS)
+#ifndef MQ_OCC_SHADE
+#define MQ_OCC_SHADE 2
+#endif
+#ifndef MQ_OCC_TRACE
+#define MQ_OCC_TRACE 6
+#endif
 
 struct RayHit { uint32_t tri; float t, u, v; };
 
@@ -142,72 +149,114 @@ MQ_DEV uint32_t box4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_
     return mask;
 }
 
+// Per-lane traversal state.  trav_step() performs ONE node visit (pop the nearest pending child,
+// intersect its 8 children, test the triangles of the leaves that were hit); traverse() loops it,
+// and the persistent queue kernel interleaves steps of different rays in one wave.
+struct Trav {
+    f3 o, d;
+    float idx, idy, idz, tmax;
+    uint32_t octinv; // bit k set: direction component k is >= 0
+    uint2 G;
+    int sp;
+    RayHit hit;
+    uint32_t best_key;
+    uint32_t tmask, tbase; // triangles of the last visited node that still have to be tested
+};
+
+MQ_DEV void trav_init(Trav& t, f3 o, f3 d, float tmax) {
+    t.o = o; t.d = d; t.tmax = tmax;
+    t.idx = 1.0f / (fabsf(d.x) > 1e-20f ? d.x : (d.x < 0.0f ? -1e-20f : 1e-20f));
+    t.idy = 1.0f / (fabsf(d.y) > 1e-20f ? d.y : (d.y < 0.0f ? -1e-20f : 1e-20f));
+    t.idz = 1.0f / (fabsf(d.z) > 1e-20f ? d.z : (d.z < 0.0f ? -1e-20f : 1e-20f));
+    t.octinv = (d.x < 0.0f ? 0u : 1u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 4u);
+    t.G = make_uint2(0u, 0x80000000u);
+    t.sp = 0;
+    t.hit.tri = MQ_NIL; t.hit.t = __uint_as_float(0x7f800000u); t.hit.u = 0.0f; t.hit.v = 0.0f;
+    t.best_key = MQ_NIL;
+    t.tmask = 0; t.tbase = 0;
+}
+
+// One node visit: pops the nearest pending child, intersects its 8 children; the triangles of the
+// leaves that were hit are left in t.tmask / t.tbase.  Precondition: t.G has a pending child.
 template <bool COUNT>
-MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, float tmax, RayHit& hit, uint2* stk /* &lds[0][lane] */,
-                     unsigned long long* spill, Ctr& ctr) {
-    hit.tri = MQ_NIL; hit.t = __uint_as_float(0x7f800000u); hit.u = 0.0f; hit.v = 0.0f;
-    uint32_t best_key = MQ_NIL;
-    if (COUNT) ctr.rays++;
-    if (sc.n_nodes == 0) return;
-    float idx = 1.0f / (fabsf(d.x) > 1e-20f ? d.x : (d.x < 0.0f ? -1e-20f : 1e-20f));
-    float idy = 1.0f / (fabsf(d.y) > 1e-20f ? d.y : (d.y < 0.0f ? -1e-20f : 1e-20f));
-    float idz = 1.0f / (fabsf(d.z) > 1e-20f ? d.z : (d.z < 0.0f ? -1e-20f : 1e-20f));
-    const bool sx = d.x < 0.0f, sy = d.y < 0.0f, sz = d.z < 0.0f;
-    const uint32_t octinv = (sx ? 0u : 1u) | (sy ? 0u : 2u) | (sz ? 0u : 4u);
-    uint2 G = make_uint2(0u, 0x80000000u);
-    int sp = 0;
-    for (;;) {
-        // pop the nearest remaining child of the current node group
-        uint32_t bit = 31u - (uint32_t)__clz((int)G.y);
-        G.y &= ~(1u << bit);
-        if (G.y > 0x00ffffffu) {
-            if (sp < MQ_STACK_LDS) stk[sp * 64] = G;
-            else spill[sp - MQ_STACK_LDS] = ((unsigned long long)G.y << 32) | G.x;
-            sp++;
-        }
-        uint32_t slot = (bit - 24u) ^ octinv;
-        uint32_t rel = (uint32_t)__popc(G.y & 0xffu & ((1u << slot) - 1u));
-        const uint4* np = (const uint4*)(sc.nodes + (G.x + rel));
-        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        if (COUNT) ctr.nodes++;
-        float tlim = fminf(hit.t, tmax) * 1.000001f + 1e-6f;
-        float adx = __uint_as_float((n0.w & 0xffu) << 23) * idx;
-        float ady = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * idy;
-        float adz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * idz;
-        float ox = (__uint_as_float(n0.x) - o.x) * idx;
-        float oy = (__uint_as_float(n0.y) - o.y) * idy;
-        float oz = (__uint_as_float(n0.z) - o.z) * idz;
-        // near / far plane bytes per axis, by ray direction sign
-        uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
-        uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
-        uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
-        uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, octinv) |
-                      box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, octinv);
-        G.x = n1.x;
-        G.y = (hm & 0xff000000u) | (n0.w >> 24);
-        uint32_t tmask = hm & 0x00ffffffu;
-        const uint32_t tbase = n1.y;
-        while (tmask) {
-            uint32_t k = (uint32_t)__ffs((int)tmask) - 1u;
-            tmask &= tmask - 1u;
-            const uint4* tp = (const uint4*)(sc.tris + (tbase + k));
-            uint4 a = tp[0], b = tp[1], c = tp[2];
-            if (COUNT) ctr.tris++;
-            float t = 0.0f, u = 0.0f, v = 0.0f;
-            bool accept = tri_isect(o, d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
-                                    F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
-                                    F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), t, u, v);
-            accept = accept && (t < tmax) && (t < hit.t || (t == hit.t && c.y < best_key));
-            if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, c.y, u, v);
-            if (accept) { hit.t = t; hit.u = u; hit.v = v; hit.tri = tbase + k; best_key = c.y; }
-        }
-        if (G.y <= 0x00ffffffu) {
-            if (sp == 0) break;
-            sp--;
-            if (sp < MQ_STACK_LDS) G = stk[sp * 64];
-            else { unsigned long long e = spill[sp - MQ_STACK_LDS]; G = make_uint2((uint32_t)e, (uint32_t)(e >> 32)); }
-        }
+MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane] */, unsigned long long* spill, Ctr& ctr) {
+    const bool sx = !(t.octinv & 1u), sy = !(t.octinv & 2u), sz = !(t.octinv & 4u);
+    uint2 G = t.G;
+    uint32_t bit = 31u - (uint32_t)__clz((int)G.y);
+    G.y &= ~(1u << bit);
+    if (G.y > 0x00ffffffu) {
+        if (t.sp < MQ_STACK_LDS) stk[t.sp * 64] = G;
+        else spill[t.sp - MQ_STACK_LDS] = ((unsigned long long)G.y << 32) | G.x;
+        t.sp++;
     }
+    uint32_t slot = (bit - 24u) ^ t.octinv;
+    uint32_t rel = (uint32_t)__popc(G.y & 0xffu & ((1u << slot) - 1u));
+    const uint4* np = (const uint4*)(sc.nodes + (G.x + rel));
+    uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    if (COUNT) ctr.nodes++;
+    float tlim = fminf(t.hit.t, t.tmax) * 1.000001f + 1e-6f;
+    float adx = __uint_as_float((n0.w & 0xffu) << 23) * t.idx;
+    float ady = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * t.idy;
+    float adz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * t.idz;
+    float ox = (__uint_as_float(n0.x) - t.o.x) * t.idx;
+    float oy = (__uint_as_float(n0.y) - t.o.y) * t.idy;
+    float oz = (__uint_as_float(n0.z) - t.o.z) * t.idz;
+    // near / far plane bytes per axis, by ray direction sign
+    uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
+    uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
+    uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
+    uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, t.octinv) |
+                  box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, t.octinv);
+    G.x = n1.x;
+    G.y = (hm & 0xff000000u) | (n0.w >> 24);
+    t.G = G;
+    t.tmask = hm & 0x00ffffffu;
+    t.tbase = n1.y;
+}
+
+// Tests ONE pending triangle (lowest bit of t.tmask).
+template <bool COUNT>
+MQ_DEV void trav_tri(const MqSceneDev& sc, Trav& t, Ctr& ctr) {
+    uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
+    t.tmask &= t.tmask - 1u;
+    const uint4* tp = (const uint4*)(sc.tris + (t.tbase + k));
+    uint4 a = tp[0], b = tp[1], c = tp[2];
+    if (COUNT) ctr.tris++;
+    float tt = 0.0f, u = 0.0f, v = 0.0f;
+    bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
+                            F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
+                            F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), tt, u, v);
+    accept = accept && (tt < t.tmax) && (tt < t.hit.t || (tt == t.hit.t && c.y < t.best_key));
+    if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, c.y, u, v);
+    if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = t.tbase + k; t.best_key = c.y; }
+}
+
+// After the pending triangles are done: continue with the current group or pop the stack.
+// Returns true when the traversal is complete.
+MQ_DEV bool trav_next(Trav& t, uint2* stk, unsigned long long* spill) {
+    if (t.G.y > 0x00ffffffu) return false;
+    if (t.sp == 0) return true;
+    t.sp--;
+    if (t.sp < MQ_STACK_LDS) t.G = stk[t.sp * 64];
+    else { unsigned long long e = spill[t.sp - MQ_STACK_LDS]; t.G = make_uint2((uint32_t)e, (uint32_t)(e >> 32)); }
+    return false;
+}
+
+// returns true when the traversal is complete
+template <bool COUNT>
+MQ_DEV bool trav_step(const MqSceneDev& sc, Trav& t, uint2* stk, unsigned long long* spill, Ctr& ctr) {
+    trav_node<COUNT>(sc, t, stk, spill, ctr);
+    while (t.tmask) trav_tri<COUNT>(sc, t, ctr);
+    return trav_next(t, stk, spill);
+}
+
+template <bool COUNT>
+MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, float tmax, RayHit& hit, uint2* stk, unsigned long long* spill, Ctr& ctr) {
+    Trav t;
+    trav_init(t, o, d, tmax);
+    if (COUNT) ctr.rays++;
+    if (sc.n_nodes != 0) while (!trav_step<COUNT>(sc, t, stk, spill, ctr)) {}
+    hit = t.hit;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -493,8 +542,60 @@ MQ_DEV void load_chit(const uint32_t* src, Hit& h) { // hit.glsl.h:45-53
     h.roughness = h2f((uint16_t)(e.y >> 16));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wavefront pipeline.  One frame =
+//     mq_primary_kernel                      first hit (g-buffer node) + first direction choice
+//     R x { mq_trace_queue_kernel ;          closest hit for every queued ray (lean, high occupancy)
+//           mq_bounce_kernel }               shade the hit, learn, finish samples, choose next direction
+// with R = spp * (max_path_length - 1) rounds.  Live paths are COMPACTED between rounds: a kernel
+// appends the paths that continue to the next round's queue with one aggregated atomic per wave
+// (ballot + prefix popcount), so every kernel runs on dense, uniform work and the traversal kernel
+// keeps its own small register footprint.  Path state lives in a 160-byte record per pixel slot.
+//
+// Measured motivation (profiles/r01_*): fused into one persistent megakernel the same work took
+// 6.3 ms per 1080p frame (mixed-state divergence, 2-3 waves/SIMD), while the frame's rays alone
+// traverse in about 1.4 ms when the traversal runs as its own kernel.
+// ------------------------------------------------------------------------------------------------
+struct Path {
+    Hit cur;
+    f3 thr, fval, irr, wo;
+    float pp, m2, wo_p, bsdf, wodotn, score_sum, mc_sum_w;
+    uint32_t rng, px, py, mc_index, mc_id;
+    int seg, smp;
+    bool lm_dir_ok;
+};
+
+MQ_DEV void store_path(uint4* dst, const Path& p) {
+    dst[0] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(p.cur.prev_pos.x));
+    dst[1] = make_uint4(__float_as_uint(p.cur.prev_pos.y), __float_as_uint(p.cur.prev_pos.z), __float_as_uint(p.cur.wi.x), __float_as_uint(p.cur.wi.y));
+    dst[2] = make_uint4(__float_as_uint(p.cur.wi.z), __float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z));
+    dst[3] = make_uint4(p.cur.enc_geonormal, (uint32_t)f2h(p.cur.albedo.x) | ((uint32_t)f2h(p.cur.albedo.y) << 16), (uint32_t)f2h(p.cur.albedo.z) | ((uint32_t)f2h(p.cur.roughness) << 16), p.rng);
+    dst[4] = make_uint4(__float_as_uint(p.thr.x), __float_as_uint(p.thr.y), __float_as_uint(p.thr.z), __float_as_uint(p.pp));
+    dst[5] = make_uint4(__float_as_uint(p.fval.x), __float_as_uint(p.fval.y), __float_as_uint(p.fval.z), __float_as_uint(p.m2));
+    dst[6] = make_uint4(__float_as_uint(p.irr.x), __float_as_uint(p.irr.y), __float_as_uint(p.irr.z), p.px | (p.py << 16));
+    dst[7] = make_uint4(__float_as_uint(p.wo.x), __float_as_uint(p.wo.y), __float_as_uint(p.wo.z), __float_as_uint(p.wo_p));
+    dst[8] = make_uint4(__float_as_uint(p.bsdf), __float_as_uint(p.wodotn), __float_as_uint(p.score_sum), __float_as_uint(p.mc_sum_w));
+    dst[9] = make_uint4(p.mc_index, p.mc_id, (uint32_t)p.seg | ((uint32_t)p.smp << 8) | (p.lm_dir_ok ? 0x10000u : 0u), 0u);
+}
+MQ_DEV void load_path(const uint4* src, Path& p) {
+    uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], f = src[5], g = src[6], h = src[7], i = src[8], j = src[9];
+    p.cur.pos = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+    p.cur.prev_pos = F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+    p.cur.wi = F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+    p.cur.normal = F3(__uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
+    p.cur.enc_geonormal = d.x;
+    p.cur.albedo = F3(h2f((uint16_t)(d.y & 0xffffu)), h2f((uint16_t)(d.y >> 16)), h2f((uint16_t)(d.z & 0xffffu)));
+    p.cur.roughness = h2f((uint16_t)(d.z >> 16));
+    p.rng = d.w;
+    p.thr = F3(__uint_as_float(e.x), __uint_as_float(e.y), __uint_as_float(e.z)); p.pp = __uint_as_float(e.w);
+    p.fval = F3(__uint_as_float(f.x), __uint_as_float(f.y), __uint_as_float(f.z)); p.m2 = __uint_as_float(f.w);
+    p.irr = F3(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z)); p.px = g.w & 0xffffu; p.py = g.w >> 16;
+    p.wo = F3(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z)); p.wo_p = __uint_as_float(h.w);
+    p.bsdf = __uint_as_float(i.x); p.wodotn = __uint_as_float(i.y); p.score_sum = __uint_as_float(i.z); p.mc_sum_w = __uint_as_float(i.w);
+    p.mc_index = j.x; p.mc_id = j.y; p.seg = (int)(j.z & 0xffu); p.smp = (int)((j.z >> 8) & 0xffu); p.lm_dir_ok = (j.z & 0x10000u) != 0;
+}
+
 MQ_DEV void flush_counters(MqCountersDev* g, const Ctr& c) {
-    // wave-level reduction, then one atomic per counter per wave
     const uint32_t v[12] = {c.rays, c.nodes, c.tris, c.segments, c.guided, c.lc, c.upd_ok, c.upd_drop, c.mc_reads, c.pixels, c.lc_ok, c.lc_cancel};
     unsigned long long* dst = (unsigned long long*)g;
 #pragma unroll
@@ -505,8 +606,139 @@ MQ_DEV void flush_counters(MqCountersDev* g, const Ctr& c) {
     }
 }
 
+// Runs the "choose next direction / finish sample / restart / finish pixel" logic of
+// mcpg.comp:54-137,193-210 until the path either has a ray to trace (returns true; ro/rd in
+// path.wo and the caller derives the origin) or the pixel is complete (returns false, outputs written).
 template <bool GUIDED, bool COUNT>
-__global__ __launch_bounds__(MQ_BLOCK) void mq_render_kernel(MqSceneDev sc, MqParams P, MqFrame F) {
+MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t slot, bool need_dir, bool sample_done, Ctr& ctr) {
+    const mq_uniform& U = F.u;
+    const int K = P.mc_samples < MQ_MAX_MC_SAMPLES ? P.mc_samples : MQ_MAX_MC_SAMPLES;
+    const size_t pidx = (size_t)p.py * F.W + p.px;
+    while (need_dir || sample_done) {
+        if (need_dir) {
+            need_dir = false;
+            if (COUNT) ctr.segments++;
+            const float alpha = roughness_to_alpha(p.cur.roughness);
+            f3 wo;
+            bool rejected = false;
+            if (!GUIDED) { // mcpg.comp:59-64
+                float x0 = xorshift(p.rng), x1 = xorshift(p.rng), x2 = xorshift(p.rng);
+                wo = bsdf_sample(p.cur.wi, p.cur.normal, alpha, x0, x1, x2);
+                p.wodotn = dot(wo, p.cur.normal);
+                if (p.wodotn <= 1e-3f || dot(wo, decode_normal(p.cur.enc_geonormal)) <= 1e-3f) rejected = true;
+                else p.wo_p = bsdf_pdf(p.cur.wi, wo, p.cur.normal, alpha);
+            } else { // mcpg.comp:67-137
+                if (COUNT) ctr.guided++;
+                float scores[MQ_MAX_MC_SAMPLES]; f3 vdir[MQ_MAX_MC_SAMPLES]; float vk[MQ_MAX_MC_SAMPLES];
+                uint32_t bidx[MQ_MAX_MC_SAMPLES], bh16[MQ_MAX_MC_SAMPLES]; float xsel[MQ_MAX_MC_SAMPLES]; bool badapt[MQ_MAX_MC_SAMPLES];
+                const f3 lp = p.smp == 0 ? p.cur.prev_pos : p.cur.pos;
+                // the RNG draws of the K lookups are data independent: addresses first, then the K
+                // independent 48-byte state loads in flight together, then the reservoir
+#pragma unroll
+                for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
+                    if (i < K) {
+                        badapt[i] = xorshift(p.rng) < P.mc_samples_adaptive_prob;
+                        if (badapt[i]) mc_adaptive_buffer_index(P, U, p.rng, lp, p.cur.normal, bidx[i], bh16[i]);
+                        else mc_static_buffer_index(P, p.rng, lp, bidx[i], bh16[i]);
+                        xsel[i] = xorshift(p.rng);
+                    }
+                }
+                p.score_sum = 0.0f; p.mc_index = MQ_NIL; p.mc_id = 0; p.mc_sum_w = 0.0f;
+                MCS sel = {};
+#pragma unroll
+                for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
+                    if (i < K) {
+                        MCS st = mc_load(F.mc, bidx[i]);
+                        if (COUNT) ctr.mc_reads++;
+                        mc_finalize_load(U, st, bh16[i], !badapt[i], p.cur.pos, p.cur.normal);
+                        p.score_sum += st.sum_w;
+                        f3 d = mc_state_dir(st, p.cur.pos); float kk = mc_state_kappa(P, st, p.cur.pos);
+                        if (xsel[i] < st.sum_w / p.score_sum) {
+                            sel = st; p.mc_index = bidx[i];
+                            vdir[i] = vdir[0]; vk[i] = vk[0]; scores[i] = scores[0];
+                            scores[0] = st.sum_w; vdir[0] = d; vk[0] = kk;
+                        } else { scores[i] = st.sum_w; vdir[i] = d; vk[i] = kk; }
+                    }
+                }
+                if (p.score_sum == 0.0f || xorshift(p.rng) < P.surf_bsdf_p) { // :113-117
+                    float x0 = xorshift(p.rng), x1 = xorshift(p.rng), x2 = xorshift(p.rng);
+                    wo = bsdf_sample(p.cur.wi, p.cur.normal, alpha, x0, x1, x2);
+                    sel = mc_state_new(p.rng);
+                    p.mc_index = MQ_NIL;
+                } else {
+                    float x0 = xorshift(p.rng), x1 = xorshift(p.rng);
+                    wo = vmf_sample(vdir[0], vk[0], x0, x1);
+                }
+                p.wodotn = dot(wo, p.cur.normal);
+                if (p.wodotn <= 1e-3f || dot(wo, decode_normal(p.cur.enc_geonormal)) <= 1e-3f) rejected = true;
+                else {
+                    float g = 0.0f;
+                    if (p.score_sum > 0.0f) {
+#pragma unroll
+                        for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) if (i < K) g += scores[i] * vmf_pdf(wo, vdir[i], vk[i]);
+                        g /= p.score_sum;
+                    }
+                    p.wo_p = (p.score_sum > 0.0f ? P.surf_bsdf_p : 1.0f) * bsdf_pdf(p.cur.wi, wo, p.cur.normal, alpha) + (1.0f - P.surf_bsdf_p) * g;
+                    p.mc_id = sel.id; p.mc_sum_w = sel.sum_w;
+                    // second half of mc_light_missing (mc.glsl:34-38), evaluated now so the state need not be kept
+                    p.lm_dir_ok = false;
+                    if (p.mc_index != MQ_NIL) p.lm_dir_ok = !(dot(wo, mc_state_dir(sel, p.cur.pos)) < 0.9f + 0.1f * mc_state_mean_cos(P, sel, p.cur.pos));
+                }
+            }
+            if (rejected) sample_done = true; // `break` at mcpg.comp:63 / :125
+            else {
+                p.bsdf = bsdf_times_wodotn(p.cur.wi, wo, p.cur.normal, alpha, 0.02f); // :153 (pre-trace data only)
+                p.wo = wo;
+                return true;
+            }
+        }
+        if (sample_done) { // mcpg.comp:193-198
+            sample_done = false;
+            f3 contrib = p.fval * (1.0f / p.pp);
+            if (mfinite(contrib.x) && mfinite(contrib.y) && mfinite(contrib.z)) { p.irr = p.irr + contrib; float l = luminance(contrib); p.m2 += l * l; }
+            p.smp++;
+            if (p.smp < P.spp) {
+                load_chit(F.hits + 10 * pidx, p.cur);
+                p.thr = F3(1, 1, 1); p.fval = F3(0, 0, 0); p.pp = 1.0f; p.seg = 1;
+                need_dir = true;
+            } else { // :205-210
+                float inv = 1.0f / (float)P.spp;
+                float4 o4 = make_float4(p.irr.x * inv, p.irr.y * inv, p.irr.z * inv, p.m2 * inv);
+                *(float4*)(F.irradiance + 4 * pidx) = o4;
+                *(float4*)(F.tiles_out + 4 * (size_t)slot) = o4;
+                return false;
+            }
+        }
+    }
+    return false;
+}
+
+// Appends the lanes with `push` set to the queue of round `round`: one atomic per wave.
+MQ_DEV uint32_t queue_append(const MqFrame& F, int round, bool push) {
+    unsigned long long m = __ballot(push);
+    uint32_t my = 0;
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&F.ctrl[MQ_CTRL_QUEUE0 + round], (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        my = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    return my;
+}
+MQ_DEV void emit_ray(const MqFrame& F, int round, uint32_t q, uint32_t slot, const Path& p) {
+    f3 ro = p.cur.pos - p.cur.wi * 1e-3f; // mcpg.comp:144
+    float4* r = F.rays + 2 * (size_t)q;
+    r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    r[1] = make_float4(p.wo.x, p.wo.y, p.wo.z, 0.0f);
+    F.queue_slots[round & 1][q] = slot;
+    store_path(F.paths + 10 * (size_t)slot, p);
+}
+
+// ---- first hit: gbuffer.comp:75-131 + start of mcpg.comp:39-57 --------------------------------
+template <bool GUIDED, bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSceneDev sc, MqParams P, MqFrame F) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint2* stk = &s_stack[wave][0][lane];
@@ -514,80 +746,47 @@ __global__ __launch_bounds__(MQ_BLOCK) void mq_render_kernel(MqSceneDev sc, MqPa
     const uint32_t total = F.n_local_tiles * 64u;
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
-    const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
-    const f3 gb_sun = P.gbuffer_hide_sun ? F3(0.0f, 0.0f, 0.0f) : sun_color;
-    const int K = P.mc_samples < MQ_MAX_MC_SAMPLES ? P.mc_samples : MQ_MAX_MC_SAMPLES;
-
+    const f3 gb_sun = P.gbuffer_hide_sun ? F3(0.0f, 0.0f, 0.0f) : F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
-    // path state
-    bool active = false, exhausted = false;
-    uint32_t px = 0, py = 0, lidx = 0, rng = 0;
-    int seg = 0, smp = 0;
-    Hit cur = {};
-    f3 thr = F3(1, 1, 1), fval = F3(0, 0, 0), irr = F3(0, 0, 0);
-    float pp = 1.0f, m2 = 0.0f;
-    f3 ro = F3(0, 0, 0), rd = F3(0, 0, 1);
-    // carried over the trace of a bounce ray
-    float wo_p = 0.0f, bsdf = 0.0f, wodotn = 0.0f, score_sum = 0.0f, mc_sum_w = 0.0f;
-    uint32_t mc_index = MQ_NIL, mc_id = 0;
-    bool lm_dir_ok = false;
-
-    for (;;) {
-        // ---- (re)arm idle lanes with fresh pixels: one aggregated atomic per wave -------------
-        if (!active && !exhausted) {
-            unsigned long long idle = __ballot(1);
-            int leader = __ffsll((long long)idle) - 1;
-            uint32_t n = (uint32_t)__popcll(idle), base = 0;
-            if (lane == leader) base = atomicAdd(&F.ctrl[0], n);
-            base = __shfl(base, leader, 64);
-            uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (my < total) {
-                uint32_t ltile = my >> 6, within = my & 63u;
-                uint32_t gtile = ltile * F.world + F.rank;
-                uint32_t tx = gtile % F.tiles_x, ty = gtile / F.tiles_x;
-                px = tx * 8u + (within & 7u); py = ty * 8u + (within >> 3);
-                lidx = my;
-                active = true; seg = 0; smp = 0;
-                irr = F3(0, 0, 0); m2 = 0.0f;
-                rng = pcg4d16(px, py, U.frame, P.seed); // mcpg.comp:40
-                ro = cam_pos(U);
-                rd = camera_ray_dir((float)px, (float)py, Wf, Hf, F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]), P.fov_tan_alpha_half);
+    const uint32_t stride = gridDim.x * MQ_BLOCK;
+    const uint32_t rounds = (total + stride - 1) / stride;
+    for (uint32_t it = 0; it < rounds; it++) {
+        const uint32_t my = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        bool cont = false;
+        Path p = {};
+        if (my < total) {
+            uint32_t ltile = my >> 6, within = my & 63u;
+            uint32_t gtile = ltile * F.world + F.rank;
+            uint32_t tx = gtile % F.tiles_x, ty = gtile / F.tiles_x;
+            p.px = tx * 8u + (within & 7u); p.py = ty * 8u + (within >> 3);
+            if (p.px < F.W && p.py < F.H) {
                 if (COUNT) ctr.pixels++;
-            } else exhausted = true;
-        }
-        if (__ballot(active) == 0ull) break;
-
-        // ---- the single traversal call site ----------------------------------------------------
-        RayHit rhit;
-        rhit.tri = MQ_NIL; rhit.t = 0.0f; rhit.u = rhit.v = 0.0f;
-        const bool in_image = px < F.W && py < F.H;
-        if (active && in_image) traverse<COUNT>(sc, ro, rd, MQ_T_MAX, rhit, stk, spill, ctr);
-
-        if (active) {
-            bool need_dir = false, sample_done = false;
-            const size_t pidx = (size_t)py * F.W + px;
-            if (!in_image) { // padding lanes of edge tiles
-                active = false;
-            } else if (seg == 0) {
-                // ---- g-buffer node: gbuffer.comp:75-131 ---------------------------------------
+                const size_t pidx = (size_t)p.py * F.W + p.px;
+                p.rng = pcg4d16(p.px, p.py, U.frame, P.seed); // mcpg.comp:40
+                const f3 up = F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), fw = F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]);
+                f3 ro = cam_pos(U);
+                f3 rd = camera_ray_dir((float)p.px, (float)p.py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
+                RayHit rhit;
+                traverse<COUNT>(sc, ro, rd, MQ_T_MAX, rhit, stk, spill, ctr);
                 Hit h; h.pos = ro; h.wi = rd; h.prev_pos = ro; h.normal = F3(0, 0, 1); h.enc_geonormal = 0; h.albedo = F3(0, 0, 0); h.roughness = 0.0f;
                 f3 incident = F3(0, 0, 0), cthr = F3(1, 1, 1);
                 shade_hit(sc, P, U, rhit, cthr, incident, h, gb_sun);
                 *(uint2*)(F.gb_irr + 4 * pidx) = make_uint2((uint32_t)f2h(incident.x) | ((uint32_t)f2h(incident.y) << 16), (uint32_t)f2h(incident.z) | (0x3c00u << 16));
-                float keep = (incident.x >= 1e-5f || incident.y >= 1e-5f || incident.z >= 1e-5f) ? 0.0f : 1.0f;
+                float keep = (incident.x >= 1e-5f || incident.y >= 1e-5f || incident.z >= 1e-5f) ? 0.0f : 1.0f; // gbuffer.comp:107
                 h.albedo = rh3(rh3(h.albedo * keep) * cthr);
                 *(uint2*)(F.gb_albedo + 4 * pidx) = make_uint2((uint32_t)f2h(h.albedo.x) | ((uint32_t)f2h(h.albedo.y) << 16), (uint32_t)f2h(h.albedo.z) | (0x3c00u << 16));
-                {
+                { // gbuffer.comp:111-115
                     f3 old_dir = h.prev_pos - F3(U.prev_cam_x[0], U.prev_cam_x[1], U.prev_cam_x[2]);
                     float opx, opy;
                     camera_pixel(old_dir, Wf, Hf, F3(U.prev_cam_u[0], U.prev_cam_u[1], U.prev_cam_u[2]), F3(U.prev_cam_w[0], U.prev_cam_w[1], U.prev_cam_w[2]), P.fov_tan_alpha_half, opx, opy);
-                    *(uint32_t*)(F.gb_mv + 2 * pidx) = (uint32_t)f2h(opx - (float)px) | ((uint32_t)f2h(opy - (float)py) << 16);
+                    *(uint32_t*)(F.gb_mv + 2 * pidx) = (uint32_t)f2h(opx - (float)p.px) | ((uint32_t)f2h(opy - (float)p.py) << 16);
                 }
-                store_chit(F.hits + 10 * pidx, h);
-                {
-                    f3 up = F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), fw = F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]);
-                    f3 r_x = camera_ray_dir((float)px + 1.0f, (float)py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
-                    f3 r_y = camera_ray_dir((float)px, (float)py + 1.0f, Wf, Hf, up, fw, P.fov_tan_alpha_half);
+                __attribute__((aligned(8))) uint32_t rec[10];
+                store_chit(rec, h);
+                { uint2* d2 = (uint2*)(F.hits + 10 * pidx); const uint2* s2 = (const uint2*)rec; d2[0] = s2[0]; d2[1] = s2[1]; d2[2] = s2[2]; d2[3] = s2[3]; d2[4] = s2[4]; }
+                { // gbuffer.comp:123-130
+                    f3 r_x = camera_ray_dir((float)p.px + 1.0f, (float)p.py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
+                    f3 r_y = camera_ray_dir((float)p.px, (float)p.py + 1.0f, Wf, Hf, up, fw, P.fov_tan_alpha_half);
                     f3 gn = decode_normal(h.enc_geonormal);
                     f3 cp = cam_pos(U);
                     float lz = length(cp - h.pos);
@@ -596,170 +795,177 @@ __global__ __launch_bounds__(MQ_BLOCK) void mq_render_kernel(MqSceneDev sc, MqPa
                     float vz = length(F3(U.prev_cam_x[0], U.prev_cam_x[1], U.prev_cam_x[2]) - h.prev_pos) - lz;
                     *(uint4*)(F.gbuffer + 4 * pidx) = make_uint4(encode_normal(h.normal), __float_as_uint(lz), g0 | (g1 << 16), __float_as_uint(vz));
                 }
-                // ---- mcpg.comp:44: skip pixels whose first hit carries no albedo -------------
+                // mcpg.comp:44: pixels whose first hit carries no albedo get zero irradiance
                 if ((h.albedo.x >= 1e-7f || h.albedo.y >= 1e-7f || h.albedo.z >= 1e-7f) && P.spp > 0 && P.max_path_length > 1) {
-                    // the surface pass starts from the COMPRESSED first hit (mcpg.comp:46-47)
-                    Hit tmp = h; // compress -> decompress through registers, same values as the stored record
-                    __attribute__((aligned(8))) uint32_t rec[10];
-                    store_chit(rec, tmp);
-                    load_chit(rec, cur);
-                    thr = F3(1, 1, 1); fval = F3(0, 0, 0); pp = 1.0f; seg = 1; smp = 0;
-                    need_dir = true;
+                    load_chit(rec, p.cur); // the surface pass starts from the COMPRESSED first hit (mcpg.comp:46-47)
+                    p.thr = F3(1, 1, 1); p.fval = F3(0, 0, 0); p.pp = 1.0f; p.seg = 1; p.smp = 0; p.irr = F3(0, 0, 0); p.m2 = 0.0f;
+                    cont = advance_path<GUIDED, COUNT>(P, F, p, my, true, false, ctr);
                 } else {
-                    seg = 1; smp = P.spp; // nothing to trace: falls through to the pixel store
-                    sample_done = false;
-                    // write result now
                     float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     *(float4*)(F.irradiance + 4 * pidx) = o4;
-                    *(float4*)(F.tiles_out + 4 * (size_t)lidx) = o4;
-                    active = false;
-                }
-            } else {
-                // ---- a bounce ray returned: mcpg.comp:141-189 ----------------------------------
-                Hit next; next.wi = rd; next.pos = ro; next.prev_pos = ro; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
-                f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
-                shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
-                f3 lc_incident;
-                if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
-                else { lc_incident = rh3(throughput * light_cache_get(P, U, F.lc, rng, next.pos, next.normal)); if (COUNT) ctr.lc++; }
-                thr = thr * bsdf;
-                if (P.use_light_cache_tail) fval = thr * (seg < P.max_path_length - 1 ? incident : lc_incident);
-                else fval = thr * incident;
-                pp *= wo_p;
-                thr = thr * throughput;
-                if (GUIDED) { // mcpg.comp:165-181
-                    float mc_f = luminance((lc_incident * bsdf) * (1.0f / wo_p));
-                    if (mfinite(mc_f)) {
-                        float den = P.quirk_lc_max_wo_p ? mmax(wo_p, 10.0f) : mmax(wo_p, 1e-6f);
-                        light_cache_update(P, U, F.lc, rng, cur.pos, cur.normal, ((lc_incident * (cur.albedo * MQ_INV_PI)) * wodotn) * (1.0f / den), ctr);
-                        if (COUNT) ctr.lc++;
-                        if (xorshift(rng) * score_sum < mc_f * (float)P.mc_samples) {
-                            // mc_state_add_sample + send_update_to_buffer, mc.glsl:159-222
-                            uint32_t index = mc_index;
-                            if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, rng, cur.pos, cur.normal, index, h16); }
-                            uint32_t old = atomicAdd(&F.upd_count[index], 1u);
-                            bool ok = old < MQ_MAX_UPDATES;
-                            uint32_t q = 0;
-                            if (ok) { q = atomicAdd(&F.ctrl[1], 1u); ok = q < F.queue_cap; }
-                            if (ok) {
-                                f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
-                                uint4* e = (uint4*)(F.queue + q);
-                                uint32_t prev = atomicExch(&F.upd_head[index], q + 1u);
-                                e[0] = make_uint4(__float_as_uint(cur.pos.x), __float_as_uint(cur.pos.y), __float_as_uint(cur.pos.z), __float_as_uint(mc_f));
-                                e[1] = make_uint4(__float_as_uint(next.pos.x), __float_as_uint(next.pos.y), __float_as_uint(next.pos.z), mc_id);
-                                e[2] = make_uint4(__float_as_uint(cur.normal.x), __float_as_uint(cur.normal.y), __float_as_uint(cur.normal.z), __float_as_uint(U.cl_time));
-                                e[3] = make_uint4((uint32_t)f2h(mv.x) | ((uint32_t)f2h(mv.y) << 16), (uint32_t)f2h(mv.z) | (old << 16), index, prev);
-                                ctr.upd_ok++;
-                            } else { atomicSub(&F.upd_count[index], 1u); ctr.upd_drop++; }
-                        } else if (P.mc_fast_recovery && mc_index != MQ_NIL && !(mc_f > 1e-3f * mc_sum_w) && lm_dir_ok) {
-                            F.mc[mc_index].sum_w = 0.0f; // mcpg.comp:177
-                        }
-                    }
-                }
-                thr = thr * next.albedo; // :184
-                cur = next;
-                if ((thr.x < 1e-7f && thr.y < 1e-7f && thr.z < 1e-7f) || (fval.x > 1e-7f || fval.y > 1e-7f || fval.z > 1e-7f)) sample_done = true;
-                else { seg++; if (seg < P.max_path_length) need_dir = true; else sample_done = true; }
-            }
-
-            // ---- choose the next direction / finish samples (mcpg.comp:54-137,193-210) --------
-            while (active && (need_dir || sample_done)) {
-                if (need_dir) {
-                    need_dir = false;
-                    if (COUNT) ctr.segments++;
-                    const float alpha = roughness_to_alpha(cur.roughness);
-                    f3 wo;
-                    bool rejected = false;
-                    if (!GUIDED) { // mcpg.comp:59-64
-                        float x0 = xorshift(rng), x1 = xorshift(rng), x2 = xorshift(rng);
-                        wo = bsdf_sample(cur.wi, cur.normal, alpha, x0, x1, x2);
-                        wodotn = dot(wo, cur.normal);
-                        if (wodotn <= 1e-3f || dot(wo, decode_normal(cur.enc_geonormal)) <= 1e-3f) rejected = true;
-                        else wo_p = bsdf_pdf(cur.wi, wo, cur.normal, alpha);
-                    } else { // mcpg.comp:67-137
-                        if (COUNT) ctr.guided++;
-                        float scores[MQ_MAX_MC_SAMPLES]; f3 vdir[MQ_MAX_MC_SAMPLES]; float vk[MQ_MAX_MC_SAMPLES];
-                        uint32_t bidx[MQ_MAX_MC_SAMPLES], bh16[MQ_MAX_MC_SAMPLES]; float xsel[MQ_MAX_MC_SAMPLES]; bool badapt[MQ_MAX_MC_SAMPLES];
-                        const f3 lp = smp == 0 ? cur.prev_pos : cur.pos;
-                        // all RNG draws of the K lookups are data independent: issue addresses first,
-                        // then the K independent 48-byte state loads, then run the reservoir.
-#pragma unroll
-                        for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
-                            if (i < K) {
-                                badapt[i] = xorshift(rng) < P.mc_samples_adaptive_prob;
-                                if (badapt[i]) mc_adaptive_buffer_index(P, U, rng, lp, cur.normal, bidx[i], bh16[i]);
-                                else mc_static_buffer_index(P, rng, lp, bidx[i], bh16[i]);
-                                xsel[i] = xorshift(rng);
-                            }
-                        }
-                        score_sum = 0.0f; mc_index = MQ_NIL; mc_id = 0; mc_sum_w = 0.0f;
-                        MCS sel = {};
-#pragma unroll
-                        for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
-                            if (i < K) {
-                                MCS st = mc_load(F.mc, bidx[i]);
-                                if (COUNT) ctr.mc_reads++;
-                                mc_finalize_load(U, st, bh16[i], !badapt[i], cur.pos, cur.normal);
-                                score_sum += st.sum_w;
-                                f3 d = mc_state_dir(st, cur.pos); float kk = mc_state_kappa(P, st, cur.pos);
-                                if (xsel[i] < st.sum_w / score_sum) {
-                                    sel = st; mc_index = bidx[i];
-                                    vdir[i] = vdir[0]; vk[i] = vk[0]; scores[i] = scores[0];
-                                    scores[0] = st.sum_w; vdir[0] = d; vk[0] = kk;
-                                } else { scores[i] = st.sum_w; vdir[i] = d; vk[i] = kk; }
-                            }
-                        }
-                        if (score_sum == 0.0f || xorshift(rng) < P.surf_bsdf_p) { // :113-117
-                            float x0 = xorshift(rng), x1 = xorshift(rng), x2 = xorshift(rng);
-                            wo = bsdf_sample(cur.wi, cur.normal, alpha, x0, x1, x2);
-                            sel = mc_state_new(rng);
-                            mc_index = MQ_NIL;
-                        } else {
-                            float x0 = xorshift(rng), x1 = xorshift(rng);
-                            wo = vmf_sample(vdir[0], vk[0], x0, x1);
-                        }
-                        wodotn = dot(wo, cur.normal);
-                        if (wodotn <= 1e-3f || dot(wo, decode_normal(cur.enc_geonormal)) <= 1e-3f) rejected = true;
-                        else {
-                            float g = 0.0f;
-                            if (score_sum > 0.0f) {
-#pragma unroll
-                                for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) if (i < K) g += scores[i] * vmf_pdf(wo, vdir[i], vk[i]);
-                                g /= score_sum;
-                            }
-                            wo_p = (score_sum > 0.0f ? P.surf_bsdf_p : 1.0f) * bsdf_pdf(cur.wi, wo, cur.normal, alpha) + (1.0f - P.surf_bsdf_p) * g;
-                            mc_id = sel.id; mc_sum_w = sel.sum_w;
-                            // second half of mc_light_missing (mc.glsl:34-38), evaluated now so the state need not stay live
-                            lm_dir_ok = false;
-                            if (mc_index != MQ_NIL) lm_dir_ok = !(dot(wo, mc_state_dir(sel, cur.pos)) < 0.9f + 0.1f * mc_state_mean_cos(P, sel, cur.pos));
-                        }
-                    }
-                    if (rejected) sample_done = true; // `break` at mcpg.comp:63 / :125
-                    else {
-                        bsdf = bsdf_times_wodotn(cur.wi, wo, cur.normal, alpha, 0.02f); // :153 (depends on pre-trace data only)
-                        ro = cur.pos - cur.wi * 1e-3f; // :144
-                        rd = wo;
-                    }
-                }
-                if (sample_done) { // mcpg.comp:193-198
-                    sample_done = false;
-                    f3 contrib = fval * (1.0f / pp);
-                    if (mfinite(contrib.x) && mfinite(contrib.y) && mfinite(contrib.z)) { irr = irr + contrib; float l = luminance(contrib); m2 += l * l; }
-                    smp++;
-                    if (smp < P.spp) {
-                        load_chit(F.hits + 10 * pidx, cur);
-                        thr = F3(1, 1, 1); fval = F3(0, 0, 0); pp = 1.0f; seg = 1;
-                        need_dir = true;
-                    } else { // :205-210
-                        float inv = 1.0f / (float)P.spp;
-                        float4 o4 = make_float4(irr.x * inv, irr.y * inv, irr.z * inv, m2 * inv);
-                        *(float4*)(F.irradiance + 4 * pidx) = o4;
-                        *(float4*)(F.tiles_out + 4 * (size_t)lidx) = o4;
-                        active = false;
-                    }
+                    *(float4*)(F.tiles_out + 4 * (size_t)my) = o4;
                 }
             }
         }
+        uint32_t q = queue_append(F, 0, cont);
+        if (cont) emit_ray(F, 0, q, my, p);
+    }
+    if (COUNT || GUIDED) flush_counters(F.counters, ctr);
+}
+
+// ---- closest hit for every queued ray ------------------------------------------------------------
+// Persistent waves with dynamic ray fetch: a lane whose ray is finished takes the next ray of its
+// wave's pool instead of idling until the longest traversal of the wave ends; pools are refilled
+// MQ_TRACE_CHUNK rays at a time with one atomic per wave, so the shared head word sees ~n/256 atomics.
+#define MQ_TRACE_CHUNK 256u
+#ifndef MQ_TRI_VOTE
+#define MQ_TRI_VOTE 16u
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
+    __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
+    const int lane = threadIdx.x & 63;
+    uint2* stk = &s_stack[threadIdx.x >> 6][0][lane];
+    const uint32_t gid = blockIdx.x * MQ_BLOCK + threadIdx.x;
+    unsigned long long* spill = F.stack_spill + (size_t)gid * MQ_SPILL_ENTRIES;
+    const uint32_t n = F.ctrl[MQ_CTRL_QUEUE0 + round];
+    Ctr ctr = {};
+    uint32_t pool_next = 0, pool_end = 0; // wave-uniform
+    bool exhausted = n == 0 || sc.n_nodes == 0;
+    if (sc.n_nodes == 0) { // empty scene: every ray misses
+        for (uint32_t q = gid; q < n; q += gridDim.x * MQ_BLOCK) F.ray_hits[q] = make_uint4(MQ_NIL, 0x7f800000u, 0u, 0u);
+    }
+    bool busy = false;
+    uint32_t q = 0;
+    Trav t;
+    trav_init(t, F3(0, 0, 0), F3(0, 0, 1), 0.0f);
+    for (;;) {
+        unsigned long long idle = __ballot(!busy);
+        if (idle) {
+            if (pool_next == pool_end && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&F.ctrl[MQ_CTRL_HEAD0 + round], MQ_TRACE_CHUNK);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= n) { exhausted = true; pool_next = pool_end = 0; }
+                else { pool_next = base; pool_end = base + MQ_TRACE_CHUNK < n ? base + MQ_TRACE_CHUNK : n; }
+            }
+            const uint32_t avail = pool_end - pool_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!busy && rank < avail) {
+                q = pool_next + rank;
+                float4 o = F.rays[2 * (size_t)q], d = F.rays[2 * (size_t)q + 1];
+                trav_init(t, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), MQ_T_MAX);
+                busy = true;
+                if (COUNT) ctr.rays++;
+            }
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            pool_next += n_idle < avail ? n_idle : avail;
+        }
+        if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
+        // node phase: lanes without pending triangles visit one node
+        const bool want_node = busy && t.tmask == 0;
+        if (want_node) trav_node<COUNT>(sc, t, stk, spill, ctr);
+        // triangle phase, by wave vote: run it only when enough lanes have triangles pending (or no
+        // lane could use another node phase), so the expensive test executes at useful occupancy
+        const bool has_tri = busy && t.tmask != 0;
+        const unsigned long long tv = __ballot(has_tri);
+        const uint32_t ntri = (uint32_t)__popcll(tv);
+        const uint32_t nbusy = (uint32_t)__popcll(__ballot(busy));
+        if (ntri >= MQ_TRI_VOTE || ntri == nbusy) {
+            if (has_tri) trav_tri<COUNT>(sc, t, ctr);
+        }
+        if (busy && t.tmask == 0) {
+            if (trav_next(t, stk, spill)) {
+                F.ray_hits[q] = make_uint4(t.hit.tri, __float_as_uint(t.hit.t), __float_as_uint(t.hit.u), __float_as_uint(t.hit.v));
+                busy = false;
+            }
+        }
+    }
+    if (COUNT) { // counted separately so the trace kernel's own algorithmic bytes can be priced
+        flush_counters(F.counters, ctr);
+        uint32_t v[3] = {ctr.rays, ctr.nodes, ctr.tris};
+        for (int i = 0; i < 3; i++) {
+            uint32_t x = v[i];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0 && x) atomicAdd(&F.counters->q_rays + i, (unsigned long long)x);
+        }
+    }
+}
+
+// ---- a bounce ray returned: mcpg.comp:141-189, then the next direction ---------------------------
+template <bool GUIDED, bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSceneDev sc, MqParams P, MqFrame F, int round) {
+    const mq_uniform& U = F.u;
+    const uint32_t n = F.ctrl[MQ_CTRL_QUEUE0 + round];
+    const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
+    Ctr ctr = {};
+    const uint32_t stride = gridDim.x * MQ_BLOCK;
+    const uint32_t iters = (n + stride - 1) / stride;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t q = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        bool cont = false;
+        uint32_t slot = 0;
+        Path p = {};
+        if (q < n) {
+            slot = F.queue_slots[round & 1][q];
+            load_path(F.paths + 10 * (size_t)slot, p);
+            uint4 hq = F.ray_hits[q];
+            RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
+            Hit next; next.wi = p.wo; next.pos = p.cur.pos - p.cur.wi * 1e-3f; next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
+            f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
+            shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
+            f3 lc_incident; // mcpg.comp:149
+            if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
+            else { lc_incident = rh3(throughput * light_cache_get(P, U, F.lc, p.rng, next.pos, next.normal)); if (COUNT) ctr.lc++; }
+            p.thr = p.thr * p.bsdf;
+            if (P.use_light_cache_tail) p.fval = p.thr * (p.seg < P.max_path_length - 1 ? incident : lc_incident);
+            else p.fval = p.thr * incident;
+            p.pp *= p.wo_p;
+            p.thr = p.thr * throughput;
+            if (GUIDED) { // mcpg.comp:165-181
+                float mc_f = luminance((lc_incident * p.bsdf) * (1.0f / p.wo_p));
+                if (mfinite(mc_f)) {
+                    float den = P.quirk_lc_max_wo_p ? mmax(p.wo_p, 10.0f) : mmax(p.wo_p, 1e-6f);
+#ifndef MQ_ABL_NOLC
+                    light_cache_update(P, U, F.lc, p.rng, p.cur.pos, p.cur.normal, ((lc_incident * (p.cur.albedo * MQ_INV_PI)) * p.wodotn) * (1.0f / den), ctr);
+#endif
+                    if (COUNT) ctr.lc++;
+#ifdef MQ_ABL_NOENQ
+                    if (false) {
+#else
+                    if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
+#endif
+                        // mc_state_add_sample + send_update_to_buffer, mc.glsl:159-222
+                        uint32_t index = p.mc_index;
+                        if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, p.rng, p.cur.pos, p.cur.normal, index, h16); }
+                        uint32_t old = atomicAdd(&F.upd_count[index], 1u);
+                        bool ok = old < MQ_MAX_UPDATES;
+                        uint32_t uq = 0;
+                        if (ok) { uq = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES], 1u); ok = uq < F.queue_cap; }
+                        if (ok) {
+                            f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
+                            uint4* e = (uint4*)(F.queue + uq);
+                            uint32_t prev = atomicExch(&F.upd_head[index], uq + 1u);
+                            e[0] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(mc_f));
+                            e[1] = make_uint4(__float_as_uint(next.pos.x), __float_as_uint(next.pos.y), __float_as_uint(next.pos.z), p.mc_id);
+                            e[2] = make_uint4(__float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z), __float_as_uint(U.cl_time));
+                            e[3] = make_uint4((uint32_t)f2h(mv.x) | ((uint32_t)f2h(mv.y) << 16), (uint32_t)f2h(mv.z) | (old << 16), index, prev);
+                            ctr.upd_ok++;
+                        } else { atomicSub(&F.upd_count[index], 1u); ctr.upd_drop++; }
+                    } else if (P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
+                        F.mc[p.mc_index].sum_w = 0.0f; // mcpg.comp:177
+                    }
+                }
+            }
+            p.thr = p.thr * next.albedo; // :184
+            p.cur = next;
+            bool need_dir = false, sample_done = false;
+            if ((p.thr.x < 1e-7f && p.thr.y < 1e-7f && p.thr.z < 1e-7f) || (p.fval.x > 1e-7f || p.fval.y > 1e-7f || p.fval.z > 1e-7f)) sample_done = true;
+            else { p.seg++; if (p.seg < P.max_path_length) need_dir = true; else sample_done = true; }
+            cont = advance_path<GUIDED, COUNT>(P, F, p, slot, need_dir, sample_done, ctr);
+        }
+        uint32_t qn = queue_append(F, round + 1, cont);
+        if (cont) emit_ray(F, round + 1, qn, slot, p);
     }
     if (COUNT || GUIDED) flush_counters(F.counters, ctr);
 }
@@ -779,7 +985,7 @@ MQ_DEV void mc_update(MCS& s, f3 pos, float w, f3 target, const uint16_t* mv) { 
 
 __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
     const mq_uniform& U = F.u;
-    uint32_t n = F.ctrl[1] < F.queue_cap ? F.ctrl[1] : F.queue_cap;
+    uint32_t n = F.ctrl[MQ_CTRL_UPDATES] < F.queue_cap ? F.ctrl[MQ_CTRL_UPDATES] : F.queue_cap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint4* e = (const uint4*)(F.queue + i);
         uint4 e3 = e[3];
@@ -896,9 +1102,18 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage; used by mq_api.cpp)
 // ------------------------------------------------------------------------------------------------
-int mq_launch_render(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s) {
-    if (guided) { if (count) mq_render_kernel<true, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_render_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
-    else { if (count) mq_render_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_render_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
+int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s) {
+    if (guided) { if (count) mq_primary_kernel<true, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_primary_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
+    else { if (count) mq_primary_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_primary_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
+    return (int)hipGetLastError();
+}
+int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s) {
+    if (count) mq_trace_queue_kernel<true><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round); else mq_trace_queue_kernel<false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
+    return (int)hipGetLastError();
+}
+int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s) {
+    if (guided) { if (count) mq_bounce_kernel<true, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); else mq_bounce_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); }
+    else { if (count) mq_bounce_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); else mq_bounce_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); }
     return (int)hipGetLastError();
 }
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
@@ -920,13 +1135,6 @@ int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, ui
 int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int no, const float* in, float* out, uint32_t n, hipStream_t s) {
     mq_math_kernel<<<(n + 255) / 256, 256, 0, s>>>(sc, P, op, ni, no, in, out, n);
     return (int)hipGetLastError();
-}
-int mq_render_blocks_per_cu(bool guided, bool count) {
-    int n = 0;
-    hipError_t e;
-    if (guided) e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<true, true>, MQ_BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<true, false>, MQ_BLOCK, 0);
-    else e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<false, true>, MQ_BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mq_render_kernel<false, false>, MQ_BLOCK, 0);
-    return e == hipSuccess ? n : 0;
 }
 int mq_render_block_size() { return MQ_BLOCK; }
 int mq_spill_entries() { return MQ_SPILL_ENTRIES; }

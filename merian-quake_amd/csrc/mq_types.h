@@ -1,6 +1,7 @@
 // mq_types.h -- POD layouts shared by the host code and the HIP kernels of libmqhip.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 #include "../../include/mq.h"
 
@@ -20,6 +21,11 @@
 #define MQ_MAX_MC_SAMPLES 8        // kernel register budget; reference UI allows 0..30
 #define MQ_BARY_EPS 3.814697265625e-06f
 #define MQ_NIL 0xffffffffu
+#define MQ_CTRL_UPDATES 1
+#define MQ_CTRL_QUEUE0 2
+#define MQ_MAX_ROUNDS 30
+#define MQ_CTRL_HEAD0 (MQ_CTRL_QUEUE0 + MQ_MAX_ROUNDS + 1)
+#define MQ_CTRL_WORDS 64
 
 // 80-byte compressed 8-wide BVH node (Ylitie et al. 2017 layout).
 struct MqNode {
@@ -134,7 +140,7 @@ struct MqSceneDev {
 
 struct MqCountersDev {
     unsigned long long rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
-        mc_updates_dropped, mc_state_reads, pixels, lc_ok, lc_cancel;
+        mc_updates_dropped, mc_state_reads, pixels, lc_ok, lc_cancel, q_rays, q_nodes, q_tris, q_paths;
 };
 
 // Per-frame launch block of the render kernel.
@@ -159,8 +165,15 @@ struct MqFrame {
     uint32_t* upd_head;    // per mc slot, index+1 of the newest queue entry
     MqUpdate* queue;
     uint32_t queue_cap;
-    // control words: [0] next pixel, [1] queue tail
+    // control words: [MQ_CTRL_UPDATES] update-queue tail, [MQ_CTRL_QUEUE0 + r] ray count of round r,
+    // [MQ_CTRL_HEAD0 + r] fetch head of round r's traversal kernel
     uint32_t* ctrl;
+    // wavefront state: 160-byte path records per pixel slot, rays / hits per queue position,
+    // ping-pong queues of pixel slots
+    uint4* paths;
+    float4* rays;
+    uint4* ray_hits;
+    uint32_t* queue_slots[2];
     MqCountersDev* counters;
     // traversal stack spill area: MQ_SPILL_ENTRIES 8-byte entries per resident lane
     unsigned long long* stack_spill;

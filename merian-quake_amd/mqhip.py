@@ -53,7 +53,7 @@ class IoDesc(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "tris", "segments", "guided_segments", "lc_touches",
-                                          "mc_updates_accepted", "mc_updates_dropped", "mc_state_reads", "pixels")]
+                                          "mc_updates_accepted", "mc_updates_dropped", "mc_state_reads", "pixels", "queue_rays", "queue_nodes", "queue_tris")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -66,7 +66,7 @@ class MqError(RuntimeError):
 
 
 def load_library(path=None):
-    path = path or LIB_PATH
+    path = path or os.environ.get("MQHIP_LIB") or LIB_PATH  # MQHIP_LIB: A/B builds of the same library
     if not os.path.exists(path):
         raise ImportError("libmqhip.so not built (%s): run __graft_entry__.build() or `make -C merian-quake_amd`" % path)
     # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  A process must end up with
@@ -110,6 +110,7 @@ def load_library(path=None):
         "mq_last_frame_ms": (i32, [P, f32p, f32p, f32p]),
         "mq_timing_reset": (i32, [P]),
         "mq_timing_get": (i32, [P, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "mq_timing_get_detail": (i32, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mq_enable_counters": (i32, [P, i32]),
         "mq_get_counters": (i32, [P, C.POINTER(Counters)]),
         "mq_reset_state": (i32, [P]),
@@ -297,6 +298,11 @@ class Context:
         n, a, b = C.c_uint32(), C.c_double(), C.c_double()
         self._chk(self.lib.mq_timing_get(self.h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value, b.value
+
+    def timing_detail(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.mq_timing_get_detail(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(primary_ms=a.value, trace_ms=b.value, bounce_ms=c.value)
 
     def enable_counters(self, on):
         self._chk(self.lib.mq_enable_counters(self.h, 1 if on else 0))
