@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "mq_host.h"
+#include "mq_device.h" // host-callable grid_width(): the per-level tables must carry the kernels' own float results
 
 // launchers implemented in mq_kernels.hip
 int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s);
@@ -262,6 +263,11 @@ void props_to_params(mq_ctx* c) {
     P.seed = c->props.seed;
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
+    P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
+    for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
+        P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
+        P.lc_inv_width_lut[l] = 1.0f / grid_width(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_min_width, P.lc_grid_power, l);
+    }
     c->params_dirty = false;
 }
 
@@ -288,7 +294,7 @@ void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     for (int i = 0; i < MQ_OUT_COUNT; i++) { d->bytes_per_pixel[i] = k_bpp[i]; d->bytes[i] = px * k_bpp[i]; }
     d->bytes[MQ_OUT_TILES] = (size_t)tpr * 64 * 16;
     size_t mc_total = (size_t)c->props.mc_adaptive_buffer_size + c->props.mc_static_buffer_size; // render_mcpg.cpp:59
-    d->state_bytes_markovchain = mc_total * sizeof(MqMCState) + mc_total * 8;
+    d->state_bytes_markovchain = mc_total * sizeof(MqMCState) + mc_total * 8; // states + per-slot count and chain head of the update queue
     d->state_bytes_lightcache = (size_t)c->props.lc_buffer_size * sizeof(MqLCCell);
     size_t local_px = (size_t)tpr * 64;
     size_t segs = local_px * (size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1);
@@ -347,7 +353,7 @@ int mq_set_property(mq_ctx* c, const char* key, double value) {
     const PropDesc* d = find_prop(key);
     if (!d) return fail(c, MQ_EUNKNOWN_KEY, std::string("unknown property: ") + key);
     if (!strcmp(key, "mc samples") && (value < 0 || value > MQ_MAX_MC_SAMPLES)) return fail(c, MQ_EINVAL, "mc samples must be in [0, 8] in this build");
-    if (d->type == PT_OPTION) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
+    if (d->type == PT_OPTION && !(!strcmp(key, "debug output") && value >= 100)) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
     bool changed = prop_set(c->props, *d, value);
     if (changed) c->params_dirty = true;
     if (changed && d->reconnect) { c->connected = false; return 1; } // NEEDS_RECONNECT, render_mcpg.cpp:567-575

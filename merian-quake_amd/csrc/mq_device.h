@@ -13,6 +13,11 @@
 #include "mq_types.h"
 
 #define MQ_DEV __device__ __forceinline__
+#define MQ_HD __host__ __device__ __forceinline__
+
+// bit casts usable on host and device
+MQ_HD float mq_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+MQ_HD uint32_t mq_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 struct f3 { float x, y, z; };
 MQ_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -32,9 +37,9 @@ MQ_DEV float mmix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 MQ_DEV bool mfinite(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
 
 // ---- transcendental replacements (polynomials, no hardware approximations) ------------------
-MQ_DEV float mq_exp2(float x) {
+MQ_HD float mq_exp2(float x) {
     if (!(x >= -126.0f)) return (x != x) ? x : 0.0f;
-    if (x >= 128.0f) return __uint_as_float(0x7f800000u);
+    if (x >= 128.0f) return mq_u2f(0x7f800000u);
     float n = floorf(x + 0.5f);
     float f = x - n;
     float y = f * 0.693147182464599609375f;
@@ -47,18 +52,18 @@ MQ_DEV float mq_exp2(float x) {
     p = p * y + 1.0f;
     p = p * y + 1.0f;
     int e = (int)n;
-    if (e > 127) return (p * 2.0f) * __uint_as_float((uint32_t)(e - 1 + 127) << 23);
-    return p * __uint_as_float((uint32_t)(e + 127) << 23);
+    if (e > 127) return (p * 2.0f) * mq_u2f((uint32_t)(e - 1 + 127) << 23);
+    return p * mq_u2f((uint32_t)(e + 127) << 23);
 }
-MQ_DEV float mq_log2(float x) {
+MQ_HD float mq_log2(float x) {
     if (x != x) return x;
-    if (!(x > 0.0f)) return __uint_as_float(0xff800000u);
-    if (x == __uint_as_float(0x7f800000u)) return x;
+    if (!(x > 0.0f)) return mq_u2f(0xff800000u);
+    if (x == mq_u2f(0x7f800000u)) return x;
     float bias = 0.0f;
     if (x < 1.17549435e-38f) { x = x * 16777216.0f; bias = -24.0f; }
-    uint32_t b = __float_as_uint(x);
+    uint32_t b = mq_f2u(x);
     int e = (int)(b >> 23) - 127;
-    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+    float m = mq_u2f((b & 0x007fffffu) | 0x3f800000u);
     if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
     float f = m - 1.0f;
     float s = f / (2.0f + f);
@@ -71,9 +76,9 @@ MQ_DEV float mq_log2(float x) {
     float ln_m = 2.0f * s * p;
     return ((float)e + bias) + ln_m * 1.44269502162933349609375f;
 }
-MQ_DEV float mq_exp(float x) { return mq_exp2(x * 1.44269502162933349609375f); }
-MQ_DEV float mq_log(float x) { return mq_log2(x) * 0.693147182464599609375f; }
-MQ_DEV float mq_pow(float x, float y) {
+MQ_HD float mq_exp(float x) { return mq_exp2(x * 1.44269502162933349609375f); }
+MQ_HD float mq_log(float x) { return mq_log2(x) * 0.693147182464599609375f; }
+MQ_HD float mq_pow(float x, float y) {
     if (x == 0.0f) return (y == 0.0f) ? 1.0f : 0.0f;
     return mq_exp2(y * mq_log2(x));
 }
@@ -170,6 +175,16 @@ MQ_DEV float vmf_pdf(f3 w, f3 mu, float kappa) {
     float e2k = mq_exp(-2.0f * kappa);
     return kappa * MQ_INV_2PI / (1.0f - e2k) * mq_exp(kappa * (dot(mu, w) - 1.0f));
 }
+// the direction-independent factor of vmf_pdf, same operations: kappa * INV_2PI / (1 - e^{-2 kappa})
+MQ_DEV float vmf_norm(float kappa) {
+    if (!(kappa > 1e-4f)) return MQ_INV_4PI;
+    float e2k = mq_exp(-2.0f * kappa);
+    return kappa * MQ_INV_2PI / (1.0f - e2k);
+}
+MQ_DEV float vmf_pdf_normed(f3 w, f3 mu, float kappa, float norm) {
+    if (!(kappa > 1e-4f)) return MQ_INV_4PI;
+    return norm * mq_exp(kappa * (dot(mu, w) - 1.0f));
+}
 MQ_DEV f3 vmf_sample(f3 mu, float kappa, float xi0, float xi1) {
     float wz;
     if (!(kappa > 1e-4f)) wz = 1.0f - 2.0f * xi0;
@@ -258,12 +273,26 @@ MQ_DEV uint32_t hash2_u32(uint32_t x) {
     return x;
 }
 struct i3 { int x, y, z; };
-MQ_DEV i3 grid_idx_interpolate(f3 pos, float width, float xi) {
+// `inv_width` = 1.0f / width (IEEE division, precomputed on the host or in-kernel)
+MQ_DEV i3 grid_idx_interpolate(f3 pos, float inv_width, float xi) {
     i3 r;
-    r.x = (int)floorf(pos.x / width + xi);
-    r.y = (int)floorf(pos.y / width + xi);
-    r.z = (int)floorf(pos.z / width + xi);
+    r.x = (int)floorf(pos.x * inv_width + xi);
+    r.y = (int)floorf(pos.y * inv_width + xi);
+    r.z = (int)floorf(pos.z * inv_width + xi);
     return r;
+}
+// floor(-log2(1 - xi)) for xi = k * 2^-24 (mc.glsl:70), exact in integers
+MQ_DEV uint32_t level_jitter(float xi) {
+    uint32_t m = 16777216u - (uint32_t)(xi * 16777216.0f);
+    uint32_t fl = 31u - (uint32_t)__clz((int)m);
+    return (m & (m - 1u)) ? 23u - fl : 24u - fl;
+}
+// multiply-high range reduction of a 32-bit hash to [0, size)
+MQ_DEV uint32_t reduce_range(uint32_t h, uint32_t size) { return __umulhi(h, size); }
+// grid cell width of a level (mc.glsl:73,75; light_cache.glsl:21,23) -- also evaluated on the host to fill the per-level tables
+MQ_HD float grid_width(int type, float steps, float minw, float power, uint32_t level) {
+    if (type == 0) return minw * mq_pow(power, (float)level / steps);
+    return mq_pow((float)level / steps, power) + minw;
 }
 MQ_DEV uint32_t normal_face(f3 n) {
     float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
@@ -274,9 +303,9 @@ MQ_DEV uint32_t normal_face(f3 n) {
 MQ_DEV uint32_t hash3(i3 c, uint32_t salt) {
     return hash_u32((uint32_t)c.x + hash_u32((uint32_t)c.y + hash_u32((uint32_t)c.z + salt)));
 }
-MQ_DEV uint32_t hash_grid(i3 c, uint32_t size) { return hash3(c, 0x51ed270bu) % size; }
+MQ_DEV uint32_t hash_grid(i3 c, uint32_t size) { return reduce_range(hash3(c, 0x51ed270bu), size); }
 MQ_DEV uint32_t hash_grid_normal_level(i3 c, f3 n, uint32_t level, uint32_t size) {
-    return hash3(c, hash_u32(level * 8u + normal_face(n) + 0x2545f491u)) % size;
+    return reduce_range(hash3(c, hash_u32(level * 8u + normal_face(n) + 0x2545f491u)), size);
 }
 MQ_DEV uint32_t hash2_3(i3 c, uint32_t salt) {
     return hash2_u32((uint32_t)c.x * 0x9e3779b1u + hash2_u32((uint32_t)c.y * 0x85ebca77u + hash2_u32((uint32_t)c.z * 0xc2b2ae3du + salt)));

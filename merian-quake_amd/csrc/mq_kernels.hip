@@ -22,6 +22,8 @@
 #define MQ_STACK_LDS 12
 #endif
 #define MQ_SPILL_ENTRIES (64 - MQ_STACK_LDS)
+// per-wave LDS region of the primary kernel in uint2 rows: max(stack entries, 6 floats x MQ_MAX_MC_SAMPLES lobes / 2)
+#define MQ_LDS_DWORDS2 ((6 * MQ_MAX_MC_SAMPLES + 1) / 2 > MQ_STACK_LDS ? (6 * MQ_MAX_MC_SAMPLES + 1) / 2 : MQ_STACK_LDS)
 #ifndef MQ_OCC_SHADE
 #define MQ_OCC_SHADE 2
 #endif
@@ -406,23 +408,25 @@ MQ_DEV uint32_t grid_level(int type, float steps, float tan_half, float minw, fl
     else lv = steps * mq_pow(mmax(w - minw, 0.0f), 1.0f / power);
     return (uint32_t)floorf(lv + 0.5f);
 }
-MQ_DEV float grid_width(int type, float steps, float minw, float power, uint32_t level) {
-    if (type == 0) return minw * mq_pow(power, (float)level / steps);
-    return mq_pow((float)level / steps, power) + minw;
+MQ_DEV float mc_inv_width(const MqParams& P, uint32_t level) {
+    if (level < MQ_WIDTH_LUT) return P.mc_inv_width_lut[level];
+    return 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, level);
+}
+MQ_DEV float lc_inv_width(const MqParams& P, uint32_t level) {
+    if (level < MQ_WIDTH_LUT) return P.lc_inv_width_lut[level];
+    return 1.0f / grid_width(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_min_width, P.lc_grid_power, level);
 }
 MQ_DEV f3 cam_pos(const mq_uniform& U) { return F3(U.cam_x[0], U.cam_x[1], U.cam_x[2]); }
 
 MQ_DEV void mc_adaptive_buffer_index(const MqParams& P, const mq_uniform& U, uint32_t& rng, f3 pos, f3 normal, uint32_t& index, uint32_t& hash16) {
     uint32_t level = grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, cam_pos(U), pos);
-    float xi = xorshift(rng);
-    level += (uint32_t)(-mq_log2(1.0f - xi));
-    float width = grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, level);
-    i3 g = grid_idx_interpolate(pos, width, xorshift(rng));
+    level += level_jitter(xorshift(rng)); // mc.glsl:70
+    i3 g = grid_idx_interpolate(pos, mc_inv_width(P, level), xorshift(rng));
     index = hash_grid_normal_level(g, normal, level, P.mc_adaptive_buffer_size);
     hash16 = hash2_grid_level(g, level) & 0xffffu;
 }
 MQ_DEV void mc_static_buffer_index(const MqParams& P, uint32_t& rng, f3 pos, uint32_t& index, uint32_t& hash16) {
-    i3 g = grid_idx_interpolate(pos, P.mc_static_grid_width, xorshift(rng));
+    i3 g = grid_idx_interpolate(pos, P.mc_static_inv_width, xorshift(rng));
     index = hash_grid(g, P.mc_static_buffer_size) + P.mc_adaptive_buffer_size;
     hash16 = hash2_grid(g) & 0xffffu;
 }
@@ -476,8 +480,7 @@ MQ_DEV void mc_finalize_load(const mq_uniform& U, MCS& s, uint32_t hash16, bool 
 
 // ---- light cache (light_cache.glsl:31-84) ------------------------------------------------------
 MQ_DEV void lc_address(const MqParams& P, uint32_t& rng, uint32_t level, f3 pos, f3 normal, uint32_t& idx, uint32_t& chk) {
-    float width = grid_width(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_min_width, P.lc_grid_power, level);
-    i3 g = grid_idx_interpolate(pos, width, xorshift(rng));
+    i3 g = grid_idx_interpolate(pos, lc_inv_width(P, level), xorshift(rng));
     idx = hash_grid_normal_level(g, normal, level, P.lc_buffer_size);
     chk = hash2_grid_level(g, level);
 }
@@ -497,17 +500,20 @@ MQ_DEV f3 light_cache_get(const MqParams& P, const mq_uniform& U, const MqLCCell
     light_cache_get_level(P, lc, rng, irr, N, lc_level(P, U, pos), pos, normal);
     return irr;
 }
+// light_cache.glsl:54-84.  The reference takes a per-cell try-lock (atomicExchange of the frame
+// number) and DROPS the update when the lock is contended; this version needs no lock word (see the
+// store below).  Frame 0 cancels every update, as the reference does (its zero-initialised lock
+// word equals params.frame, light_cache.glsl:59-64).
 MQ_DEV void light_cache_update(const MqParams& P, const mq_uniform& U, MqLCCell* lc, uint32_t& rng, f3 pos, f3 normal, f3 irr, Ctr& ctr) {
     uint32_t level = lc_level(P, U, pos), idx, chk;
     lc_address(P, rng, level, pos, normal, idx, chk);
+    if (U.frame == 0u) { ctr.lc_cancel++; return; }
     MqLCCell* cell = lc + idx;
-    uint32_t old = atomicExch(&cell->lock, U.frame);
-    if (old == U.frame) { ctr.lc_cancel++; return; }
-    const volatile uint32_t* vc = (const volatile uint32_t*)cell;
-    uint4 c = make_uint4(vc[0], vc[1], vc[2], vc[3]);
+    uint4 c = *(const uint4*)cell;
     uint16_t i0 = (uint16_t)(c.z & 0xffffu), i1 = (uint16_t)(c.z >> 16), i2 = (uint16_t)(c.w & 0xffffu);
     f3 cur; uint32_t N;
-    if (c.x != chk || h_bad(i0) || h_bad(i1) || h_bad(i2)) {
+    const bool rekey = c.x != chk || h_bad(i0) || h_bad(i1) || h_bad(i2);
+    if (rekey) { // :68-75 seed from the next coarser level
         f3 ci; uint32_t cn;
         light_cache_get_level(P, lc, rng, ci, cn, level + 1, pos, normal);
         cur = rh3(ci); N = cn;
@@ -515,14 +521,16 @@ MQ_DEV void light_cache_update(const MqParams& P, const mq_uniform& U, MqLCCell*
     N = N + 1 < MQ_LC_MAX_N ? N + 1 : MQ_LC_MAX_N;
     float a = mmax(1.0f / (float)N, MQ_LC_MIN_ALPHA);
     uint32_t o0 = f2h(mmix(cur.x, irr.x, a)), o1 = f2h(mmix(cur.y, irr.y, a)), o2 = f2h(mmix(cur.z, irr.z, a));
-    // hash + irradiance + N in one 16-byte store; the lock word is released by the same store
-    *(uint4*)cell = make_uint4(chk, 0u, o0 | (o1 << 16), o2 | (N << 16));
+    const uint32_t nz = o0 | (o1 << 16), nw = o2 | (N << 16);
+    // One aligned store publishes the cell: 16 bytes when the cell is (re)keyed, else the 8-byte
+    // (irradiance, N) payload.  Two lanes racing on one cell lose one of the two updates -- the
+    // reference drops contended updates too -- and scattered atomics (about 20 G/s on this chip)
+    // would otherwise bound the kernel.
+    if (rekey) *(uint4*)cell = make_uint4(chk, 0u, nz, nw);
+    else *(uint2*)&cell->irr[0] = make_uint2(nz, nw);
     ctr.lc_ok++;
 }
 
-// ------------------------------------------------------------------------------------------------
-// the render megakernel
-// ------------------------------------------------------------------------------------------------
 MQ_DEV void store_chit(uint32_t* dst, const Hit& h) { // hit.glsl.h:34-43, 40-byte record
     uint32_t m0 = f2h(h.pos.x - h.prev_pos.x), m1 = f2h(h.pos.y - h.prev_pos.y), m2 = f2h(h.pos.z - h.prev_pos.z);
     uint2* d2 = (uint2*)dst; // 40-byte records are 8-byte aligned
@@ -610,7 +618,7 @@ MQ_DEV void flush_counters(MqCountersDev* g, const Ctr& c) {
 // mcpg.comp:54-137,193-210 until the path either has a ray to trace (returns true; ro/rd in
 // path.wo and the caller derives the origin) or the pixel is complete (returns false, outputs written).
 template <bool GUIDED, bool COUNT>
-MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t slot, bool need_dir, bool sample_done, Ctr& ctr) {
+MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t slot, bool need_dir, bool sample_done, float* lobes /* LDS, &buf[0][lane] */, Ctr& ctr) {
     const mq_uniform& U = F.u;
     const int K = P.mc_samples < MQ_MAX_MC_SAMPLES ? P.mc_samples : MQ_MAX_MC_SAMPLES;
     const size_t pidx = (size_t)p.py * F.W + p.px;
@@ -629,36 +637,38 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                 else p.wo_p = bsdf_pdf(p.cur.wi, wo, p.cur.normal, alpha);
             } else { // mcpg.comp:67-137
                 if (COUNT) ctr.guided++;
-                float scores[MQ_MAX_MC_SAMPLES]; f3 vdir[MQ_MAX_MC_SAMPLES]; float vk[MQ_MAX_MC_SAMPLES];
-                uint32_t bidx[MQ_MAX_MC_SAMPLES], bh16[MQ_MAX_MC_SAMPLES]; float xsel[MQ_MAX_MC_SAMPLES]; bool badapt[MQ_MAX_MC_SAMPLES];
+                // The K lookups run as a rolled loop (code size: the instruction cache is the scarce
+                // resource of these kernels); the lobes (score, direction, kappa) live in LDS at
+                // lobes[(6 * i + c) * 64] so that K may be a run-time value without indexed VGPRs.
+                // The 48-byte state of lookup i + 1 is requested before state i is processed.
                 const f3 lp = p.smp == 0 ? p.cur.prev_pos : p.cur.pos;
-                // the RNG draws of the K lookups are data independent: addresses first, then the K
-                // independent 48-byte state loads in flight together, then the reservoir
-#pragma unroll
-                for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
-                    if (i < K) {
-                        badapt[i] = xorshift(p.rng) < P.mc_samples_adaptive_prob;
-                        if (badapt[i]) mc_adaptive_buffer_index(P, U, p.rng, lp, p.cur.normal, bidx[i], bh16[i]);
-                        else mc_static_buffer_index(P, p.rng, lp, bidx[i], bh16[i]);
-                        xsel[i] = xorshift(p.rng);
-                    }
-                }
                 p.score_sum = 0.0f; p.mc_index = MQ_NIL; p.mc_id = 0; p.mc_sum_w = 0.0f;
                 MCS sel = {};
-#pragma unroll
-                for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) {
-                    if (i < K) {
-                        MCS st = mc_load(F.mc, bidx[i]);
-                        if (COUNT) ctr.mc_reads++;
-                        mc_finalize_load(U, st, bh16[i], !badapt[i], p.cur.pos, p.cur.normal);
-                        p.score_sum += st.sum_w;
-                        f3 d = mc_state_dir(st, p.cur.pos); float kk = mc_state_kappa(P, st, p.cur.pos);
-                        if (xsel[i] < st.sum_w / p.score_sum) {
-                            sel = st; p.mc_index = bidx[i];
-                            vdir[i] = vdir[0]; vk[i] = vk[0]; scores[i] = scores[0];
-                            scores[0] = st.sum_w; vdir[0] = d; vk[0] = kk;
-                        } else { scores[i] = st.sum_w; vdir[i] = d; vk[i] = kk; }
+                uint32_t bi_next = 0, h16_next = 0; bool adapt_next = false; float xsel_next = 0.0f;
+                MCS st_next = {};
+#pragma nounroll
+                for (int i = -1; i < K; i++) { // iteration i requests state i + 1, then processes state i
+                    MCS st = st_next;
+                    const uint32_t bi = bi_next, h16 = h16_next; const bool adapt = adapt_next; const float xsel = xsel_next;
+                    if (i + 1 < K) { // RNG draws stay in stream order: [grid, level, cell | cell, select] per lookup
+                        adapt_next = xorshift(p.rng) < P.mc_samples_adaptive_prob;
+                        if (adapt_next) mc_adaptive_buffer_index(P, U, p.rng, lp, p.cur.normal, bi_next, h16_next);
+                        else mc_static_buffer_index(P, p.rng, lp, bi_next, h16_next);
+                        xsel_next = xorshift(p.rng);
+                        st_next = mc_load(F.mc, bi_next);
                     }
+                    if (i < 0) continue;
+                    if (COUNT) ctr.mc_reads++;
+                    mc_finalize_load(U, st, h16, !adapt, p.cur.pos, p.cur.normal);
+                    p.score_sum += st.sum_w;
+                    f3 d = mc_state_dir(st, p.cur.pos); float kk = mc_state_kappa(P, st, p.cur.pos);
+                    float* li = lobes + (6 * i) * 64;
+                    const float nrm = vmf_norm(kk);
+                    if (xsel < st.sum_w / p.score_sum) { // NaN compares false; selected lobe moves to slot 0 (mcpg.comp:99-105)
+                        sel = st; p.mc_index = bi;
+                        if (i > 0) { li[0] = lobes[0]; li[64] = lobes[64]; li[128] = lobes[128]; li[192] = lobes[192]; li[256] = lobes[256]; li[320] = lobes[320]; }
+                        lobes[0] = st.sum_w; lobes[64] = d.x; lobes[128] = d.y; lobes[192] = d.z; lobes[256] = kk; lobes[320] = nrm;
+                    } else { li[0] = st.sum_w; li[64] = d.x; li[128] = d.y; li[192] = d.z; li[256] = kk; li[320] = nrm; }
                 }
                 if (p.score_sum == 0.0f || xorshift(p.rng) < P.surf_bsdf_p) { // :113-117
                     float x0 = xorshift(p.rng), x1 = xorshift(p.rng), x2 = xorshift(p.rng);
@@ -667,15 +677,18 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                     p.mc_index = MQ_NIL;
                 } else {
                     float x0 = xorshift(p.rng), x1 = xorshift(p.rng);
-                    wo = vmf_sample(vdir[0], vk[0], x0, x1);
+                    wo = vmf_sample(F3(lobes[64], lobes[128], lobes[192]), lobes[256], x0, x1);
                 }
                 p.wodotn = dot(wo, p.cur.normal);
                 if (p.wodotn <= 1e-3f || dot(wo, decode_normal(p.cur.enc_geonormal)) <= 1e-3f) rejected = true;
                 else {
                     float g = 0.0f;
                     if (p.score_sum > 0.0f) {
-#pragma unroll
-                        for (int i = 0; i < MQ_MAX_MC_SAMPLES; i++) if (i < K) g += scores[i] * vmf_pdf(wo, vdir[i], vk[i]);
+#pragma nounroll
+                        for (int i = 0; i < K; i++) {
+                            const float* li = lobes + (6 * i) * 64;
+                            g += li[0] * vmf_pdf_normed(wo, F3(li[64], li[128], li[192]), li[256], li[320]);
+                        }
                         g /= p.score_sum;
                     }
                     p.wo_p = (p.score_sum > 0.0f ? P.surf_bsdf_p : 1.0f) * bsdf_pdf(p.cur.wi, wo, p.cur.normal, alpha) + (1.0f - P.surf_bsdf_p) * g;
@@ -739,9 +752,11 @@ MQ_DEV void emit_ray(const MqFrame& F, int round, uint32_t q, uint32_t slot, con
 // ---- first hit: gbuffer.comp:75-131 + start of mcpg.comp:39-57 --------------------------------
 template <bool GUIDED, bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSceneDev sc, MqParams P, MqFrame F) {
-    __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
+    // one LDS region per wave, used first as traversal stack, then as lobe storage of the direction choice
+    __shared__ uint2 s_lds[MQ_WAVES][MQ_LDS_DWORDS2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2* stk = &s_stack[wave][0][lane];
+    uint2* stk = &s_lds[wave][0][lane];
+    float* lobes = GUIDED ? (float*)&s_lds[wave][0][0] + lane : nullptr;
     unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * MQ_BLOCK + threadIdx.x) * MQ_SPILL_ENTRIES;
     const uint32_t total = F.n_local_tiles * 64u;
     const mq_uniform& U = F.u;
@@ -799,7 +814,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 if ((h.albedo.x >= 1e-7f || h.albedo.y >= 1e-7f || h.albedo.z >= 1e-7f) && P.spp > 0 && P.max_path_length > 1) {
                     load_chit(rec, p.cur); // the surface pass starts from the COMPRESSED first hit (mcpg.comp:46-47)
                     p.thr = F3(1, 1, 1); p.fval = F3(0, 0, 0); p.pp = 1.0f; p.seg = 1; p.smp = 0; p.irr = F3(0, 0, 0); p.m2 = 0.0f;
-                    cont = advance_path<GUIDED, COUNT>(P, F, p, my, true, false, ctr);
+                    cont = advance_path<GUIDED, COUNT>(P, F, p, my, true, false, lobes, ctr);
                 } else {
                     float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     *(float4*)(F.irradiance + 4 * pidx) = o4;
@@ -895,6 +910,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
 // ---- a bounce ray returned: mcpg.comp:141-189, then the next direction ---------------------------
 template <bool GUIDED, bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSceneDev sc, MqParams P, MqFrame F, int round) {
+    __shared__ float s_lobes[GUIDED ? MQ_WAVES : 1][GUIDED ? 6 * MQ_MAX_MC_SAMPLES : 1][64];
+    float* lobes = GUIDED ? &s_lobes[threadIdx.x >> 6][0][threadIdx.x & 63] : nullptr;
     const mq_uniform& U = F.u;
     const uint32_t n = F.ctrl[MQ_CTRL_QUEUE0 + round];
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
@@ -910,10 +927,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             slot = F.queue_slots[round & 1][q];
             load_path(F.paths + 10 * (size_t)slot, p);
             uint4 hq = F.ray_hits[q];
+            const int abl = P.debug_output_selector; // >= 101: timing ablation stages (diagnostic only)
+            if (abl == 101) { F.tiles_out[4 * (size_t)slot] = p.thr.x + __uint_as_float(hq.y); continue; }
             RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
             Hit next; next.wi = p.wo; next.pos = p.cur.pos - p.cur.wi * 1e-3f; next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
             f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
             shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
+            if (abl == 102) { F.tiles_out[4 * (size_t)slot] = incident.x + next.albedo.x + next.pos.x + throughput.x; continue; }
             f3 lc_incident; // mcpg.comp:149
             if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
             else { lc_incident = rh3(throughput * light_cache_get(P, U, F.lc, p.rng, next.pos, next.normal)); if (COUNT) ctr.lc++; }
@@ -922,47 +942,50 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             else p.fval = p.thr * incident;
             p.pp *= p.wo_p;
             p.thr = p.thr * throughput;
+            if (abl == 103) { F.tiles_out[4 * (size_t)slot] = p.thr.x + p.fval.x + lc_incident.x + next.pos.x; continue; }
             if (GUIDED) { // mcpg.comp:165-181
                 float mc_f = luminance((lc_incident * p.bsdf) * (1.0f / p.wo_p));
                 if (mfinite(mc_f)) {
                     float den = P.quirk_lc_max_wo_p ? mmax(p.wo_p, 10.0f) : mmax(p.wo_p, 1e-6f);
 #ifndef MQ_ABL_NOLC
+                    if (abl != 105 && abl != 107)
                     light_cache_update(P, U, F.lc, p.rng, p.cur.pos, p.cur.normal, ((lc_incident * (p.cur.albedo * MQ_INV_PI)) * p.wodotn) * (1.0f / den), ctr);
 #endif
                     if (COUNT) ctr.lc++;
-#ifdef MQ_ABL_NOENQ
-                    if (false) {
-#else
-                    if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
-#endif
+                    if (abl == 106 || abl == 107) {
+                    } else if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
                         // mc_state_add_sample + send_update_to_buffer, mc.glsl:159-222
                         uint32_t index = p.mc_index;
                         if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, p.rng, p.cur.pos, p.cur.normal, index, h16); }
-                        uint32_t old = atomicAdd(&F.upd_count[index], 1u);
-                        bool ok = old < MQ_MAX_UPDATES;
-                        uint32_t uq = 0;
-                        if (ok) { uq = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES], 1u); ok = uq < F.queue_cap; }
-                        if (ok) {
+                        // Soft cap: a slot that already holds MQ_MAX_UPDATES entries this frame takes no more
+                        // (mc.glsl:169-184).  The count is read past L1 and bumped without waiting for the
+                        // result, so only one memory round trip sits on the path; racing lanes may overshoot
+                        // by a few entries and the update pass enforces the exact cap on arrival order.
+                        uint32_t cnt = __hip_atomic_load(&F.upd_count[index], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (cnt < MQ_MAX_UPDATES) {
+                            if (abl != 109) __hip_atomic_fetch_add(&F.upd_count[index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
-                            uint4* e = (uint4*)(F.queue + uq);
-                            uint32_t prev = atomicExch(&F.upd_head[index], uq + 1u);
-                            e[0] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(mc_f));
-                            e[1] = make_uint4(__float_as_uint(next.pos.x), __float_as_uint(next.pos.y), __float_as_uint(next.pos.z), p.mc_id);
-                            e[2] = make_uint4(__float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z), __float_as_uint(U.cl_time));
-                            e[3] = make_uint4((uint32_t)f2h(mv.x) | ((uint32_t)f2h(mv.y) << 16), (uint32_t)f2h(mv.z) | (old << 16), index, prev);
-                            ctr.upd_ok++;
-                        } else { atomicSub(&F.upd_count[index], 1u); ctr.upd_drop++; }
-                    } else if (P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
+                            uint32_t uq = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES], 1u);
+                            if (uq < F.queue_cap) {
+                                uint4* e = (uint4*)(F.queue + uq);
+                                e[0] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(mc_f));
+                                e[1] = make_uint4(__float_as_uint(next.pos.x), __float_as_uint(next.pos.y), __float_as_uint(next.pos.z), p.mc_id);
+                                e[2] = make_uint4(__float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z), __float_as_uint(U.cl_time));
+                                e[3] = make_uint4((uint32_t)f2h(mv.x) | ((uint32_t)f2h(mv.y) << 16), (uint32_t)f2h(mv.z), index, 0u);
+                            }
+                        } else ctr.upd_drop++;
+                    } else if (abl != 108 && P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
                         F.mc[p.mc_index].sum_w = 0.0f; // mcpg.comp:177
                     }
                 }
             }
             p.thr = p.thr * next.albedo; // :184
             p.cur = next;
+            if (abl == 104) { F.tiles_out[4 * (size_t)slot] = p.thr.x + p.fval.x + next.pos.x + __uint_as_float(p.rng); continue; }
             bool need_dir = false, sample_done = false;
             if ((p.thr.x < 1e-7f && p.thr.y < 1e-7f && p.thr.z < 1e-7f) || (p.fval.x > 1e-7f || p.fval.y > 1e-7f || p.fval.z > 1e-7f)) sample_done = true;
             else { p.seg++; if (p.seg < P.max_path_length) need_dir = true; else sample_done = true; }
-            cont = advance_path<GUIDED, COUNT>(P, F, p, slot, need_dir, sample_done, ctr);
+            cont = advance_path<GUIDED, COUNT>(P, F, p, slot, need_dir, sample_done, lobes, ctr);
         }
         uint32_t qn = queue_append(F, round + 1, cont);
         if (cont) emit_ray(F, round + 1, qn, slot, p);
@@ -983,18 +1006,36 @@ MQ_DEV void mc_update(MCS& s, f3 pos, float w, f3 target, const uint16_t* mv) { 
     s.mv[0] = mv[0]; s.mv[1] = mv[1]; s.mv[2] = mv[2];
 }
 
+// pass A: chain the queue entries of each slot (newest first) through `next`
+__global__ __launch_bounds__(256) void mq_link_kernel(MqFrame F) {
+    uint32_t n = F.ctrl[MQ_CTRL_UPDATES] < F.queue_cap ? F.ctrl[MQ_CTRL_UPDATES] : F.queue_cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t* e3 = (uint32_t*)(F.queue + i) + 12;
+        uint32_t prev = atomicExch(&F.upd_head[e3[2]], i + 1u);
+        e3[3] = prev;
+    }
+}
+
+// pass B: the newest entry of a slot leads and replays compute_updates.comp:56-124 for the slot's
+// first MQ_MAX_UPDATES arrivals (the reference drops later arrivals at enqueue time, mc.glsl:169-184)
 __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
     const mq_uniform& U = F.u;
     uint32_t n = F.ctrl[MQ_CTRL_UPDATES] < F.queue_cap ? F.ctrl[MQ_CTRL_UPDATES] : F.queue_cap;
+    uint32_t accepted = 0, dropped = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint4* e = (const uint4*)(F.queue + i);
         uint4 e3 = e[3];
         uint32_t slot = e3.z;
-        // the newest entry of a slot leads: it owns the whole chain of that slot
         if (*(volatile uint32_t*)&F.upd_head[slot] != i + 1u) continue;
+        // chain length, then skip the newest arrivals beyond the cap
+        uint32_t len = 0, at = i + 1u;
+        while (at != 0u) { len++; at = ((const uint4*)(F.queue + (at - 1u)))[3].w; }
         uint32_t chain[MQ_MAX_UPDATES];
-        uint32_t count = 0, at = i + 1u;
-        while (at != 0u && count < MQ_MAX_UPDATES) { chain[count++] = at - 1u; at = ((const uint4*)(F.queue + (at - 1u)))[3].w; }
+        uint32_t count = len < MQ_MAX_UPDATES ? len : MQ_MAX_UPDATES, skip = len - count;
+        at = i + 1u;
+        for (uint32_t k = 0; k < skip; k++) at = ((const uint4*)(F.queue + (at - 1u)))[3].w;
+        for (uint32_t k = 0; k < count; k++) { chain[k] = at - 1u; at = ((const uint4*)(F.queue + (at - 1u)))[3].w; }
+        accepted += count; dropped += skip;
         uint32_t rng = pcg4d16(slot, 0u, U.frame, P.seed); // :62
         MCS mc_state = mc_load(F.mc, slot);
         float sum = 0.0f, upd_T = 0.0f;
@@ -1023,8 +1064,14 @@ __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
               new_state.hash = h16; MCS old = mc_load(F.mc, bi);
               if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
         }
-        F.upd_count[slot] = 0u; // :121-122
-        F.upd_head[slot] = 0u;
+        F.upd_head[slot] = 0u; // :121-122
+        F.upd_count[slot] = 0u;
+    }
+    // statistics: accepted / dropped-by-cap updates of this frame
+    for (int off = 32; off > 0; off >>= 1) { accepted += __shfl_down(accepted, off, 64); dropped += __shfl_down(dropped, off, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (accepted) atomicAdd(&F.counters->mc_updates_accepted, (unsigned long long)accepted);
+        if (dropped) atomicAdd(&F.counters->mc_updates_dropped, (unsigned long long)dropped);
     }
 }
 
@@ -1090,7 +1137,7 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
     case 9: o[0] = __uint_as_float(pcg4d16(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]))); break;
     case 10: { mq_uniform U = {}; U.sky_lf_ft = 0xfffe; U.sky_rt_bk = 0xffffffffu; U.sky_up_dn = 0xffffffffu;
         f3 s = get_sky(sc, P, U, F3(a[0], a[1], a[2]), F3(P.sun_color[0], P.sun_color[1], P.sun_color[2])); o[0] = s.x; o[1] = s.y; o[2] = s.z; break; }
-    case 11: { i3 g = grid_idx_interpolate(F3(a[0], a[1], a[2]), a[7], 0.5f); uint32_t lv = (uint32_t)a[6];
+    case 11: { i3 g = grid_idx_interpolate(F3(a[0], a[1], a[2]), 1.0f / a[7], 0.5f); uint32_t lv = (uint32_t)a[6];
         o[0] = __uint_as_float(hash_grid_normal_level(g, F3(a[3], a[4], a[5]), lv, __float_as_uint(a[8]))); o[1] = __uint_as_float(hash2_grid_level(g, lv)); break; }
     case 12: { f3 r = ldr_to_hdr(F3(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
     case 13: { f3 fwd = F3(a[4], a[5], a[6]), up = F3(a[7], a[8], a[9]);
@@ -1117,6 +1164,7 @@ int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, 
     return (int)hipGetLastError();
 }
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
+    mq_link_kernel<<<grid, 256, 0, s>>>(F);
     mq_apply_kernel<<<grid, 256, 0, s>>>(P, F);
     return (int)hipGetLastError();
 }

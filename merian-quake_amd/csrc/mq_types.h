@@ -21,6 +21,7 @@
 #define MQ_MAX_MC_SAMPLES 8        // kernel register budget; reference UI allows 0..30
 #define MQ_BARY_EPS 3.814697265625e-06f
 #define MQ_NIL 0xffffffffu
+#define MQ_WIDTH_LUT 48
 #define MQ_CTRL_UPDATES 1
 #define MQ_CTRL_QUEUE0 2
 #define MQ_MAX_ROUNDS 30
@@ -119,6 +120,10 @@ struct MqParams {
     uint32_t distance_mc_vertex_state_count, seed;
     int32_t gbuffer_hide_sun, quirk_lc_max_wo_p, quirk_n16_wrap;
     int32_t debug_output_selector;
+    // derived on the host with the same float operations the kernels would use (mq_api.cpp props_to_params)
+    float mc_static_inv_width;
+    float mc_inv_width_lut[MQ_WIDTH_LUT]; // 1 / width(level) of the adaptive MC grid
+    float lc_inv_width_lut[MQ_WIDTH_LUT]; // 1 / width(level) of the light-cache grid
 };
 
 struct MqGeoDev {
@@ -161,7 +166,7 @@ struct MqFrame {
     // learning state
     MqMCState* mc;
     MqLCCell* lc;
-    uint32_t* upd_count;   // per mc slot
+    uint32_t* upd_count;   // per mc slot: entries queued this frame (soft cap at enqueue, exact cap in the update pass)
     uint32_t* upd_head;    // per mc slot, index+1 of the newest queue entry
     MqUpdate* queue;
     uint32_t queue_cap;

@@ -624,7 +624,7 @@ static void mc_adaptive_buffer_index(tls_t* tl, v3 pos, v3 normal, uint32_t* ind
     const orc_params_t* p = &tl->c->p;
     uint32_t level = grid_level(p->adaptive_grid_type, p->mc_adaptive_grid_steps_per_unit_size, p->mc_adaptive_grid_tan_alpha_half, p->mc_adaptive_grid_min_width, p->mc_adaptive_grid_power, cam_x(tl->c), pos);
     float xi = X(tl);
-    level += (uint32_t)(-orc_log2(1.0f - xi)); /* mc.glsl:70 */
+    level += orc_level_jitter(xi); /* mc.glsl:70 */
     float width = grid_width(p->adaptive_grid_type, p->mc_adaptive_grid_steps_per_unit_size, p->mc_adaptive_grid_min_width, p->mc_adaptive_grid_power, level);
     i3 g = orc_grid_idx_interpolate(pos, width, X(tl));
     *index = orc_hash_grid_normal_level(g, normal, level, p->mc_adaptive_buffer_size);

@@ -318,11 +318,21 @@ static inline uint32_t orc_hash2_u32(uint32_t x) { /* murmur3 finalizer */
 typedef struct { int32_t x, y, z; } i3;
 static inline i3 orc_grid_idx_interpolate(v3 pos, float width, float xi) {
     i3 r;
-    r.x = (int32_t)floorf(pos.x / width + xi);
-    r.y = (int32_t)floorf(pos.y / width + xi);
-    r.z = (int32_t)floorf(pos.z / width + xi);
+    float inv = 1.0f / width;
+    r.x = (int32_t)floorf(pos.x * inv + xi);
+    r.y = (int32_t)floorf(pos.y * inv + xi);
+    r.z = (int32_t)floorf(pos.z * inv + xi);
     return r;
 }
+/* floor(-log2(1 - xi)) for xi = k * 2^-24 (mc.glsl:70), evaluated exactly in integers:
+ * 1 - xi = m * 2^-24 with m = 2^24 - k in [1, 2^24] */
+static inline uint32_t orc_level_jitter(float xi) {
+    uint32_t m = 16777216u - (uint32_t)(xi * 16777216.0f);
+    uint32_t fl = 31u - (uint32_t)__builtin_clz(m); /* floor(log2 m) */
+    return (m & (m - 1u)) ? 23u - fl : 24u - fl;
+}
+/* map a 32-bit hash to [0, size): multiply-high range reduction */
+static inline uint32_t orc_reduce(uint32_t h, uint32_t size) { return (uint32_t)(((uint64_t)h * (uint64_t)size) >> 32); }
 /* dominant axis + sign -> 0..5 */
 static inline uint32_t orc_normal_face(v3 n) {
     float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
@@ -333,9 +343,9 @@ static inline uint32_t orc_normal_face(v3 n) {
 static inline uint32_t orc_hash3(i3 c, uint32_t salt) {
     return orc_hash_u32((uint32_t)c.x + orc_hash_u32((uint32_t)c.y + orc_hash_u32((uint32_t)c.z + salt)));
 }
-static inline uint32_t orc_hash_grid(i3 c, uint32_t size) { return orc_hash3(c, 0x51ed270bu) % size; }
+static inline uint32_t orc_hash_grid(i3 c, uint32_t size) { return orc_reduce(orc_hash3(c, 0x51ed270bu), size); }
 static inline uint32_t orc_hash_grid_normal_level(i3 c, v3 n, uint32_t level, uint32_t size) {
-    return orc_hash3(c, orc_hash_u32(level * 8u + orc_normal_face(n) + 0x2545f491u)) % size;
+    return orc_reduce(orc_hash3(c, orc_hash_u32(level * 8u + orc_normal_face(n) + 0x2545f491u)), size);
 }
 static inline uint32_t orc_hash2_3(i3 c, uint32_t salt) {
     return orc_hash2_u32((uint32_t)c.x * 0x9e3779b1u + orc_hash2_u32((uint32_t)c.y * 0x85ebca77u + orc_hash2_u32((uint32_t)c.z * 0xc2b2ae3du + salt)));

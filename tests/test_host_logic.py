@@ -102,7 +102,7 @@ def test_describe_matches_reference_buffer_sizes(mq):
     assert d.bytes[mq.OUT_HITS] == px * 40             # CompressedHit, gbuffer.cpp:39
     assert d.bytes[mq.OUT_GB_ALBEDO] == px * 8 and d.bytes[mq.OUT_GB_MV] == px * 4
     assert d.state_bytes_lightcache == 4000000 * 16
-    assert d.state_bytes_markovchain == (32777259 + 800009) * (64 + 8)  # render_mcpg.cpp:59 slots, 64 B states + 2 queue words
+    assert d.state_bytes_markovchain == (32777259 + 800009) * (64 + 8)  # render_mcpg.cpp:59 slots, 64 B states + count and chain head words
 
 
 def test_synthetic_scenes_are_deterministic_and_well_formed(mq):
