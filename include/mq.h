@@ -90,6 +90,9 @@ enum {
     MQ_OUT_GBUFFER = 4,       /* gbuffer "gbuffer": 16 B/pixel */
     MQ_OUT_HITS = 5,          /* gbuffer "hits": 40 B/pixel CompressedHit, res/shader/hit.glsl.h:19-30 */
     MQ_OUT_TILES = 6,         /* this rank's irradiance tiles, tile-major (multi-GPU exchange buffer) */
+    MQ_OUT_VOLUME = 7,        /* "volume" RGBA32F: single-scatter radiance + 2nd moment, render_mcpg.cpp:44-45 */
+    MQ_OUT_VOLUME_DEPTH = 8,  /* "volume_depth" R16F, render_mcpg.cpp:46-47 */
+    MQ_OUT_VOLUME_MV = 9,     /* "volume_mv" RG16F, render_mcpg.cpp:48-50 */
     MQ_OUT_COUNT
 };
 
@@ -97,7 +100,7 @@ typedef struct mq_io_desc {
     uint32_t width, height;
     size_t bytes[MQ_OUT_COUNT];          /* size of each output buffer */
     uint32_t bytes_per_pixel[MQ_OUT_COUNT];
-    size_t state_bytes_markovchain, state_bytes_lightcache, state_bytes_update_queue;
+    size_t state_bytes_markovchain, state_bytes_lightcache, state_bytes_update_queue, state_bytes_volume_distancemc;
 } mq_io_desc;
 
 /* work counters of the last MQ_COUNT-enabled frame (algorithmic-bytes inputs) */

@@ -30,6 +30,10 @@ int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
 int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s);
 int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int no, const float* in, float* out, uint32_t n, hipStream_t s);
+int mq_launch_forward_project(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+int mq_launch_volume_sample(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s);
+int mq_launch_volume_shade(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s);
+int mq_launch_volume_finish(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_render_block_size();
 int mq_spill_entries();
 
@@ -62,6 +66,8 @@ struct mq_ctx {
     DevBuf d_out[MQ_OUT_COUNT];
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2];
+    DevBuf d_prev_vdepth, d_dist_mc;
+    uint32_t dist_mc_n = 0;
     uint32_t queue_cap = 0;
     uint32_t mc_total = 0, lc_total = 0;
     uint64_t iteration = 0;
@@ -263,6 +269,7 @@ void props_to_params(mq_ctx* c) {
     P.seed = c->props.seed;
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
+    P.volume_forward_project = q.volume_forward_project;
     P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
     for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
@@ -275,6 +282,7 @@ void free_frame_state(mq_ctx* c) {
     for (auto& b : c->d_out) dev_free(b);
     dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
+    dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc);
     dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
@@ -283,7 +291,7 @@ void free_scene_dev(mq_ctx* c) {
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
 }
 
-const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16};
+const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4};
 
 void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     memset(d, 0, sizeof *d);
@@ -298,7 +306,10 @@ void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     d->state_bytes_lightcache = (size_t)c->props.lc_buffer_size * sizeof(MqLCCell);
     size_t local_px = (size_t)tpr * 64;
     size_t segs = local_px * (size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1);
+    segs += local_px * (size_t)std::max(0, c->props.volume_spp); // the volume pass queues Markov-chain updates too
     d->state_bytes_update_queue = segs * sizeof(MqUpdate);
+    const uint32_t gw = (uint32_t)std::max(1, c->props.distance_mc_grid_width); // render_mcpg.cpp:80-82
+    d->state_bytes_volume_distancemc = (size_t)(w / gw + 2) * (h / gw + 2) * 10 * sizeof(MqDistMC);
 }
 
 } // namespace
@@ -586,7 +597,7 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_lc, (size_t)c->lc_total * sizeof(MqLCCell)))) return r;
     if ((r = dev_alloc(c, c->d_upd_count, (size_t)c->mc_total * 4))) return r;
     if ((r = dev_alloc(c, c->d_upd_head, (size_t)c->mc_total * 4))) return r;
-    size_t segs = (size_t)c->tiles_per_rank * 64 * (size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1);
+    size_t segs = (size_t)c->tiles_per_rank * 64 * ((size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1) + (size_t)std::max(0, c->props.volume_spp));
     c->queue_cap = (uint32_t)std::min<size_t>(segs, 0x7fffffffu);
     if ((r = dev_alloc(c, c->d_queue, (size_t)c->queue_cap * sizeof(MqUpdate)))) return r;
     if ((r = dev_alloc(c, c->d_ctrl, MQ_CTRL_WORDS * 4))) return r;
@@ -600,6 +611,10 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_ray_hits, slots * 16))) return r;
     if ((r = dev_alloc(c, c->d_qslots[0], slots * 4))) return r;
     if ((r = dev_alloc(c, c->d_qslots[1], slots * 4))) return r;
+    if ((r = dev_alloc(c, c->d_prev_vdepth, (size_t)w * h * 2))) return r;
+    HIPCHK(c, hipMemset(c->d_prev_vdepth.p, 0, c->d_prev_vdepth.bytes));
+    c->dist_mc_n = (uint32_t)(d.state_bytes_volume_distancemc / sizeof(MqDistMC));
+    if ((r = dev_alloc(c, c->d_dist_mc, d.state_bytes_volume_distancemc))) return r;
     c->iteration = 0; c->connected = true; c->params_dirty = true;
     return MQ_OK;
 }
@@ -636,6 +651,8 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.stack_spill = (unsigned long long*)c->d_spill.p;
     F.paths = (uint4*)c->d_paths.p; F.rays = (float4*)c->d_rays.p; F.ray_hits = (uint4*)c->d_ray_hits.p;
     F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p;
+    F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
+    F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
 }
 
 int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
@@ -653,19 +670,23 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         HIPCHK(c, hipMemsetAsync(c->d_lc.p, 0, c->d_lc.bytes, s));
         HIPCHK(c, hipMemsetAsync(c->d_upd_count.p, 0, c->d_upd_count.bytes, s));
         HIPCHK(c, hipMemsetAsync(c->d_upd_head.p, 0, c->d_upd_head.bytes, s));
+        HIPCHK(c, hipMemsetAsync(c->d_dist_mc.p, 0, c->d_dist_mc.bytes, s)); // volume_distancemc, render_mcpg.cpp:225
+        HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, MQ_CTRL_WORDS * 4, s));
     }
+    const bool first_iteration = c->iteration == 0;
     c->iteration++;
     if (!render) { // render_mcpg.cpp:243-250
         int e = mq_launch_clear(F, s);
         if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
         return MQ_OK;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, MQ_CTRL_WORDS * 4, s));
+    HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_QUEUE0, 0, (MQ_CTRL_WORDS - MQ_CTRL_QUEUE0) * 4, s)); // queue counters; the update tail survives (volume-pass entries of the last frame)
     if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(MqCountersDev), s));
     const bool guided = !c->params.reference_mode;
     // rounds: every sample needs at most (max_path_length - 1) traced segments, render_mcpg.cpp:142-143
     const int rounds = std::max(0, c->params.spp) * std::max(0, c->params.max_path_length - 1);
-    if (rounds > MQ_MAX_ROUNDS) return fail(c, MQ_EINVAL, "spp * (max path length - 1) exceeds the round limit of this build");
+    const bool volume = c->params.volume_spp > 0 && u->cam_x[3] > 0.0f; // needs a medium: mu_t > 0
+    if (rounds + (volume ? c->params.volume_spp : 0) > MQ_MAX_ROUNDS) return fail(c, MQ_EINVAL, "spp * (max path length - 1) + volume spp exceeds the round limit of this build");
     const int timed = std::min(rounds, 8); // rounds beyond the 8th are not split out (their time lands in the update interval)
     const int slot = c->ev_slot;
     { int r = drain_slot(c, slot); if (r) return r; } // the slot's previous frame finished long ago
@@ -686,6 +707,26 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, s);
         if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     }
+    // ---- volume passes, render_mcpg.cpp:280-320 (their device time is part of the update interval) ----
+    if (guided) HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_UPDATES, 0, 4, s)); // queue consumed; volume entries start at 0
+    if (volume) {
+        const size_t px = (size_t)c->W * c->H;
+        HIPCHK(c, hipMemcpyAsync(c->d_prev_vdepth.p, c->d_out[MQ_OUT_VOLUME_DEPTH].p, px * 2, hipMemcpyDeviceToDevice, s)); // delay-1 feedback connector
+        HIPCHK(c, hipMemcpyAsync(c->d_out[MQ_OUT_VOLUME_MV].p, c->d_out[MQ_OUT_GB_MV].p, px * 4, hipMemcpyDeviceToDevice, s)); // :284-288
+        if (c->params.volume_forward_project && !first_iteration) { // :296-311
+            e = mq_launch_forward_project(c->params, F, c->grid_blocks, s);
+            if (e) return fail(c, MQ_EHIP, std::string("forward project launch: ") + hipGetErrorString((hipError_t)e));
+        }
+        for (int vs = 0; vs < c->params.volume_spp; vs++) {
+            const int r = rounds + vs;
+            e = mq_launch_volume_sample(c->scene, c->params, F, vs, r, c->count_enabled, c->grid_blocks, s);
+            if (!e) e = mq_launch_trace_queue(c->scene, F, r, c->count_enabled, c->grid_blocks, s);
+            if (!e) e = mq_launch_volume_shade(c->scene, c->params, F, vs, r, c->count_enabled, c->grid_blocks, s);
+            if (e) return fail(c, MQ_EHIP, std::string("volume launch: ") + hipGetErrorString((hipError_t)e));
+        }
+        e = mq_launch_volume_finish(c->params, F, c->grid_blocks, s);
+        if (e) return fail(c, MQ_EHIP, std::string("volume finish launch: ") + hipGetErrorString((hipError_t)e));
+    } else HIPCHK(c, hipMemsetAsync(c->d_out[MQ_OUT_VOLUME].p, 0, c->d_out[MQ_OUT_VOLUME].bytes, s));
     HIPCHK(c, hipEventRecord(ev[2 + 2 * timed], s));
     c->ev_rounds[slot] = timed;
     c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
@@ -797,9 +838,9 @@ int mq_trace_rays(mq_ctx* c, const float* org, const float* dir, uint32_t n, uin
     return r;
 }
 
-static const int k_arity[14][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}};
+static const int k_arity[16][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}};
 int mq_math_eval(mq_ctx* c, int op, const float* in, float* out, uint32_t n) {
-    if (!c || !in || !out || op < 0 || op >= 14) return MQ_EINVAL;
+    if (!c || !in || !out || op < 0 || op >= 16) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
     if (n == 0) return MQ_OK;
     HIPCHK(c, hipSetDevice(c->device));

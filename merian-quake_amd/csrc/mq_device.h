@@ -323,6 +323,66 @@ MQ_DEV f3 ldr_to_hdr(f3 c) { // raytrace.glsl:62-65
     float k = rh(l / (1.0f - l));
     return rh3(F3(rh(sqrtf(c.x)) * 2.0f * k, rh(sqrtf(c.y)) * 2.0f * k, rh(sqrtf(c.z)) * 2.0f * k));
 }
+// ---- participating medium helpers (volume.comp:34-238; DEFINED) ----------------
+MQ_DEV float transmittance_xi_max(float tmax, float mu_t) { return 1.0f - mq_exp(-mu_t * tmax); }
+MQ_DEV float transmittance_sample2(float mu_t, float xi, float xi_max) { return -mq_log(mmax(1.0f - xi * xi_max, 1e-37f)) / mu_t; }
+MQ_DEV float transmittance_pdf2(float t, float mu_t, float xi_max) { return mu_t * mq_exp(-mu_t * t) / xi_max; }
+MQ_DEV float sample_normal_box_muller(float mu, float sigma, float xi0, float xi1) {
+    float r = sqrtf(-2.0f * mq_log(mmax(xi0, 1e-37f)));
+    float c, sn;
+    mq_sincos2pi(xi1, c, sn);
+    return mu + sigma * (r * c);
+}
+MQ_DEV float sample_normal_pdf(float mu, float sigma, float x) {
+    float d = (x - mu) / sigma;
+    return mq_exp(-0.5f * (d * d)) / (sigma * 2.50662827463100024f);
+}
+// Draine phase function (Jendersie & d'Eon 2023); cos_t = dot(travel direction in, direction out)
+MQ_DEV float draine_eval(float cos_t, float g, float a) {
+    float g2 = g * g;
+    float s = 1.0f + g2 - 2.0f * g * cos_t;
+    float s32 = s * sqrtf(s);
+    return MQ_INV_4PI * ((1.0f - g2) / s32) * ((1.0f + a * (cos_t * cos_t)) / (1.0f + a * (1.0f + 2.0f * g2) / 3.0f));
+}
+MQ_DEV float draine_F(float mu, float g, float a) { // antiderivative in mu of (1 + a mu^2) s^{-3/2}
+    float A = 1.0f + g * g;
+    float s = A - 2.0f * g * mu;
+    float rs = sqrtf(s);
+    float k = a / (4.0f * (g * g));
+    return (1.0f / g) * (1.0f / rs + k * (A * A / rs + 2.0f * A * rs - s * rs / 3.0f));
+}
+MQ_DEV float draine_sample_cos(float xi, float g, float a) { // HG start + 8 clamped Newton steps on the closed-form CDF
+    if (!(fabsf(g) > 1e-3f)) return 1.0f - 2.0f * xi;
+    float g2 = g * g;
+    float q = (1.0f - g2) / (1.0f - g + 2.0f * g * xi);
+    float mu = mclamp((1.0f + g2 - q * q) / (2.0f * g), -1.0f, 1.0f);
+    float F0 = draine_F(-1.0f, g, a), F1 = draine_F(1.0f, g, a);
+    float target = F0 + xi * (F1 - F0);
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        float s = 1.0f + g2 - 2.0f * g * mu;
+        float dF = (1.0f + a * (mu * mu)) / (s * sqrtf(s));
+        mu = mclamp(mu - (draine_F(mu, g, a) - target) / dF, -1.0f, 1.0f);
+    }
+    return mu;
+}
+MQ_DEV f3 draine_sample(float xi0, float xi1, f3 wi, float g, float a) {
+    float mu = draine_sample_cos(xi0, g, a);
+    float sr = sqrtf(mmax(1.0f - mu * mu, 0.0f));
+    float c, sn;
+    mq_sincos2pi(xi1, c, sn);
+    f3 t, b;
+    make_frame(wi, t, b);
+    return (t * (sr * c) + b * (sr * sn)) + wi * mu;
+}
+MQ_DEV f3 sample_cos_frame(f3 n, float xi0, float xi1) {
+    float r = sqrtf(xi0), z = sqrtf(mmax(1.0f - xi0, 0.0f));
+    float c, sn;
+    mq_sincos2pi(xi1, c, sn);
+    f3 t, b;
+    make_frame(n, t, b);
+    return (t * (r * c) + b * (r * sn)) + n * z;
+}
 MQ_DEV f3 camera_ray_dir(float px, float py, float W, float H, f3 up, f3 fwd, float tan_half) {
     f3 right = cross(fwd, up);
     float nx = ((px + 0.5f) / W) * 2.0f - 1.0f;

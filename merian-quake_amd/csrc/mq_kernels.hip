@@ -564,6 +564,28 @@ MQ_DEV void load_chit(const uint32_t* src, Hit& h) { // hit.glsl.h:45-53
 // 6.3 ms per 1080p frame (mixed-state divergence, 2-3 waves/SIMD), while the frame's rays alone
 // traverse in about 1.4 ms when the traversal runs as its own kernel.
 // ------------------------------------------------------------------------------------------------
+// Appends a Markov-chain update (mc_state_add_sample + send_update_to_buffer, mc.glsl:159-222).
+MQ_DEV void enqueue_update(const MqParams& P, const MqFrame& F, uint32_t& rng, uint32_t index, uint32_t id, f3 pos, float w, f3 target, f3 target_mv, f3 normal, Ctr& ctr) {
+    const mq_uniform& U = F.u;
+    if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, rng, pos, normal, index, h16); }
+    // Soft cap: a slot that already holds MQ_MAX_UPDATES entries this frame takes no more
+    // (mc.glsl:169-184).  The count is read past L1 and bumped without waiting for the result, so only
+    // one memory round trip sits on the path; racing lanes may overshoot by a few entries and the
+    // update pass enforces the exact cap on arrival order.
+    uint32_t cnt = __hip_atomic_load(&F.upd_count[index], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cnt < MQ_MAX_UPDATES) {
+        __hip_atomic_fetch_add(&F.upd_count[index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t uq = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES], 1u);
+        if (uq < F.queue_cap) {
+            uint4* e = (uint4*)(F.queue + uq);
+            e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(w));
+            e[1] = make_uint4(__float_as_uint(target.x), __float_as_uint(target.y), __float_as_uint(target.z), id);
+            e[2] = make_uint4(__float_as_uint(normal.x), __float_as_uint(normal.y), __float_as_uint(normal.z), __float_as_uint(U.cl_time));
+            e[3] = make_uint4((uint32_t)f2h(target_mv.x) | ((uint32_t)f2h(target_mv.y) << 16), (uint32_t)f2h(target_mv.z), index, 0u);
+        }
+    } else ctr.upd_drop++;
+}
+
 struct Path {
     Hit cur;
     f3 thr, fval, irr, wo;
@@ -954,26 +976,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
                     if (COUNT) ctr.lc++;
                     if (abl == 106 || abl == 107) {
                     } else if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
-                        // mc_state_add_sample + send_update_to_buffer, mc.glsl:159-222
-                        uint32_t index = p.mc_index;
-                        if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, p.rng, p.cur.pos, p.cur.normal, index, h16); }
-                        // Soft cap: a slot that already holds MQ_MAX_UPDATES entries this frame takes no more
-                        // (mc.glsl:169-184).  The count is read past L1 and bumped without waiting for the
-                        // result, so only one memory round trip sits on the path; racing lanes may overshoot
-                        // by a few entries and the update pass enforces the exact cap on arrival order.
-                        uint32_t cnt = __hip_atomic_load(&F.upd_count[index], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (cnt < MQ_MAX_UPDATES) {
-                            if (abl != 109) __hip_atomic_fetch_add(&F.upd_count[index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
-                            uint32_t uq = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES], 1u);
-                            if (uq < F.queue_cap) {
-                                uint4* e = (uint4*)(F.queue + uq);
-                                e[0] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(mc_f));
-                                e[1] = make_uint4(__float_as_uint(next.pos.x), __float_as_uint(next.pos.y), __float_as_uint(next.pos.z), p.mc_id);
-                                e[2] = make_uint4(__float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z), __float_as_uint(U.cl_time));
-                                e[3] = make_uint4((uint32_t)f2h(mv.x) | ((uint32_t)f2h(mv.y) << 16), (uint32_t)f2h(mv.z), index, 0u);
-                            }
-                        } else ctr.upd_drop++;
+                        f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
+                        enqueue_update(P, F, p.rng, p.mc_index, p.mc_id, p.cur.pos, mc_f, next.pos, mv, p.cur.normal, ctr);
                     } else if (abl != 108 && P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
                         F.mc[p.mc_index].sum_w = 0.0f; // mcpg.comp:177
                     }
@@ -991,6 +995,289 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
         if (cont) emit_ray(F, round + 1, qn, slot, p);
     }
     if (COUNT || GUIDED) flush_counters(F.counters, ctr);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Single-scatter volume estimator: volume.comp:34-238, mc_distance.glsl, volume_forward_project.comp.
+// Same wavefront scheme: per sample  mq_volume_sample_kernel (camera-distance + direction choice for
+// every pixel)  ->  mq_trace_queue_kernel  ->  mq_volume_shade_kernel (contribution + learning),
+// then mq_volume_finish_kernel.  Per-pixel state: six uint4 in the path record of the pixel slot.
+// ------------------------------------------------------------------------------------------------
+struct VPath {
+    f3 irr, wo;
+    float m2, t, pd, wo_p, score_sum, dist_score_sum, mc_sum_w;
+    MqDistMC ds;
+    uint32_t rng, mc_index, mc_id, px, py;
+    bool lm_dir_ok;
+};
+MQ_DEV void store_vpath(uint4* d, const VPath& v) {
+    d[0] = make_uint4(__float_as_uint(v.irr.x), __float_as_uint(v.irr.y), __float_as_uint(v.irr.z), __float_as_uint(v.m2));
+    d[1] = make_uint4(v.rng, __float_as_uint(v.t), __float_as_uint(v.pd), __float_as_uint(v.wo_p));
+    d[2] = make_uint4(__float_as_uint(v.wo.x), __float_as_uint(v.wo.y), __float_as_uint(v.wo.z), __float_as_uint(v.score_sum));
+    d[3] = make_uint4(__float_as_uint(v.dist_score_sum), __float_as_uint(v.ds.sum_w), v.ds.N, __float_as_uint(v.ds.m0));
+    d[4] = make_uint4(__float_as_uint(v.ds.m1), v.mc_index, v.mc_id, __float_as_uint(v.mc_sum_w));
+    d[5] = make_uint4(v.px | (v.py << 16), v.lm_dir_ok ? 1u : 0u, 0u, 0u);
+}
+MQ_DEV void load_vpath(const uint4* s, VPath& v) {
+    uint4 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5];
+    v.irr = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)); v.m2 = __uint_as_float(a.w);
+    v.rng = b.x; v.t = __uint_as_float(b.y); v.pd = __uint_as_float(b.z); v.wo_p = __uint_as_float(b.w);
+    v.wo = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)); v.score_sum = __uint_as_float(c.w);
+    v.dist_score_sum = __uint_as_float(d.x); v.ds.sum_w = __uint_as_float(d.y); v.ds.N = d.z; v.ds.m0 = __uint_as_float(d.w);
+    v.ds.m1 = __uint_as_float(e.x); v.mc_index = e.y; v.mc_id = e.z; v.mc_sum_w = __uint_as_float(e.w);
+    v.px = f.x & 0xffffu; v.py = f.x >> 16; v.lm_dir_ok = (f.y & 1u) != 0;
+}
+
+MQ_DEV void distance_normal_dist(const MqDistMC& s, float& mu, float& sigma) { // mc_distance.glsl:10-16
+    float den = s.sum_w > 0.0f ? s.sum_w : 1.0f;
+    float m0 = s.m0 / den, m1 = s.m1 / den;
+    float sg = sqrtf(mmax(m1 - m0 * m0, 0.0f));
+    float n2 = (float)(s.N * s.N);
+    mu = m0; sigma = (n2 * sg + 0.2f) / (n2 + 0.2f);
+}
+MQ_DEV void distance_add_sample(MqDistMC& s, float dist, float w) { // mc_distance.glsl:19-27
+    s.N = s.N + 1 < 1024u ? s.N + 1 : 1024u;
+    float alpha = mmax(1.0f / (float)s.N, 0.01f);
+    s.sum_w = mmix(s.sum_w, w, alpha);
+    s.m0 = mmix(s.m0, w * dist, alpha); s.m1 = mmix(s.m1, w * (dist * dist), alpha);
+}
+MQ_DEV uint32_t distance_mc_index(const MqParams& P, const MqFrame& F, uint32_t& rng, float px, float py, uint32_t grid_max_x) { // mc_distance.glsl:29-44
+    float inv = 1.0f / (float)P.distance_mc_grid_width;
+    float xi = xorshift(rng);
+    int gx = (int)floorf(px * inv + xi), gy = (int)floorf(py * inv + xi);
+    uint32_t st = (uint32_t)(xorshift(rng) * (float)P.distance_mc_vertex_state_count);
+    uint32_t idx = ((uint32_t)gx + (grid_max_x + 1u) * (uint32_t)gy) * 10u + st;
+    return idx < F.dist_mc_n ? idx : F.dist_mc_n - 1u;
+}
+MQ_DEV MqDistMC distance_mc_load(const MqFrame& F, uint32_t i) {
+    float4 v = F.dist_mc[i];
+    MqDistMC s; s.sum_w = v.x; s.N = __float_as_uint(v.y); s.m0 = v.z; s.m1 = v.w;
+    return s;
+}
+
+__global__ void mq_forward_project_kernel(MqParams P, MqFrame F) { // volume_forward_project.comp:17-53
+    const mq_uniform& U = F.u;
+    const float Wf = (float)F.W, Hf = (float)F.H;
+    const uint32_t total = F.n_local_tiles * 64u;
+    for (uint32_t my = blockIdx.x * blockDim.x + threadIdx.x; my < total; my += gridDim.x * blockDim.x) {
+        uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+        uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
+        if (px >= F.W || py >= F.H) continue;
+        float prev_depth = h2f(F.prev_volume_depth[(size_t)py * F.W + px]);
+        f3 pwi = camera_ray_dir((float)px, (float)py, Wf, Hf, F3(U.prev_cam_u[0], U.prev_cam_u[1], U.prev_cam_u[2]), F3(U.prev_cam_w[0], U.prev_cam_w[1], U.prev_cam_w[2]), P.fov_tan_alpha_half);
+        f3 ppos = F3(U.prev_cam_x[0], U.prev_cam_x[1], U.prev_cam_x[2]) + pwi * prev_depth;
+        float fx, fy;
+        camera_pixel(ppos - cam_pos(U), Wf, Hf, F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]), P.fov_tan_alpha_half, fx, fy);
+        float rx = floorf(fx + 0.5f), ry = floorf(fy + 0.5f);
+        if (!(rx >= 0.0f && ry >= 0.0f && rx < Wf && ry < Hf)) continue;
+        if (prev_depth < 50.0f) continue;
+        size_t o = (size_t)(int)ry * F.W + (size_t)(int)rx;
+        *(uint32_t*)(F.volume_mv + 2 * o) = (uint32_t)f2h((float)px - rx) | ((uint32_t)f2h((float)py - ry) << 16);
+    }
+}
+
+// camera-distance sampling + direction choice (volume.comp:54-179) for sample `smp` of every pixel
+template <bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kernel(MqSceneDev sc, MqParams P, MqFrame F, int smp, int round) {
+    __shared__ float s_lobes[MQ_WAVES][6 * MQ_MAX_MC_SAMPLES][64];
+    float* lobes = &s_lobes[threadIdx.x >> 6][0][threadIdx.x & 63];
+    const mq_uniform& U = F.u;
+    const float Wf = (float)F.W, Hf = (float)F.H;
+    const uint32_t total = F.n_local_tiles * 64u;
+    const uint32_t grid_max_x = F.W / (uint32_t)P.distance_mc_grid_width + 1u;
+    const float mu_t = U.cam_x[3];
+    const int KD = P.distance_mc_samples < MQ_MAX_MC_SAMPLES ? P.distance_mc_samples : MQ_MAX_MC_SAMPLES;
+    const int K = P.mc_samples < MQ_MAX_MC_SAMPLES ? P.mc_samples : MQ_MAX_MC_SAMPLES;
+    Ctr ctr = {};
+    const uint32_t stride = gridDim.x * MQ_BLOCK;
+    const uint32_t iters = (total + stride - 1) / stride;
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t my = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        bool cont = false;
+        VPath v = {};
+        f3 first_wi = F3(0, 0, 1);
+        if (my < total) {
+            uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+            uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
+            if (px < F.W && py < F.H) {
+                const size_t pidx = (size_t)py * F.W + px;
+                if (smp == 0) { v.px = px; v.py = py; v.irr = F3(0, 0, 0); v.m2 = 0.0f; v.rng = pcg4d16(px, py, U.frame, P.seed); } // :45
+                else load_vpath(F.paths + 10 * (size_t)my, v);
+                uint4 gb = *(const uint4*)(F.gbuffer + 4 * pidx);
+                const float linear_z = __uint_as_float(gb.y);
+                first_wi = camera_ray_dir((float)px, (float)py, Wf, Hf, F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]), P.fov_tan_alpha_half);
+                const uint32_t mvp = *(const uint32_t*)(F.volume_mv + 2 * pidx);
+                const float mvx = h2f((uint16_t)(mvp & 0xffffu)), mvy = h2f((uint16_t)(mvp >> 16));
+                const float tmax_v = mmin(linear_z, P.volume_max_t);
+                bool skip = false;
+                float pd = 0.0f, t = 0.0f;
+                MqDistMC dstate; dstate.sum_w = 0.0f; dstate.N = 0; dstate.m0 = 0.0f; dstate.m1 = 0.0f;
+                float dist_score_sum = 0.0f;
+                { // :58-104 camera-distance sampling; (score, mu, sigma) of the candidates in LDS rows 0..3K-1
+                    const float xi_max = transmittance_xi_max(tmax_v, mu_t);
+#pragma nounroll
+                    for (int i = 0; i < KD; i++) {
+                        MqDistMC st; float nmu, nsg;
+                        if (smp == 0) {
+                            float qx = mclamp((float)px + mvx, 0.0f, Wf - 1.0f), qy = mclamp((float)py + mvy, 0.0f, Hf - 1.0f);
+                            st = distance_mc_load(F, distance_mc_index(P, F, v.rng, qx, qy, grid_max_x));
+                            distance_normal_dist(st, nmu, nsg);
+                            nmu -= dot(cam_pos(U) - F3(U.prev_cam_x[0], U.prev_cam_x[1], U.prev_cam_x[2]), first_wi);
+                        } else {
+                            st = distance_mc_load(F, distance_mc_index(P, F, v.rng, (float)px, (float)py, grid_max_x));
+                            distance_normal_dist(st, nmu, nsg);
+                        }
+                        float score = st.sum_w * (st.sum_w > 0.0f ? 1.0f : 0.0f) * (nmu < linear_z ? 1.0f : 0.0f);
+                        lobes[(3 * i) * 64] = score; lobes[(3 * i + 1) * 64] = nmu; lobes[(3 * i + 2) * 64] = nsg;
+                        dist_score_sum += score;
+                        if (xorshift(v.rng) < score / dist_score_sum) {
+                            dstate = st;
+                            float x0 = xorshift(v.rng), x1 = xorshift(v.rng);
+                            t = sample_normal_box_muller(nmu, nsg, x0, x1);
+                        }
+                    }
+                    if (P.dist_guide_p < xorshift(v.rng) || dist_score_sum == 0.0f) t = transmittance_sample2(mu_t, xorshift(v.rng), xi_max);
+                    else if (t >= tmax_v || t <= 0.0f) skip = true; // `continue` at :93
+                    if (!skip) {
+                        if (dist_score_sum > 0.0f) {
+#pragma nounroll
+                            for (int i = 0; i < KD; i++) pd += lobes[(3 * i) * 64] * sample_normal_pdf(lobes[(3 * i + 1) * 64], lobes[(3 * i + 2) * 64], t);
+                            pd /= dist_score_sum;
+                        }
+                        pd = (dist_score_sum > 0.0f ? (1.0f - P.dist_guide_p) : 1.0f) * transmittance_pdf2(t, mu_t, xi_max) + P.dist_guide_p * pd;
+                    }
+                }
+                if (!skip) { // :106-179 direction: Markov-chain lobes MIS'd with the Draine phase function
+                    const f3 cur_pos = cam_pos(U) + first_wi * t;
+                    const f3 nrm = -first_wi;
+                    float wo_p = 0.0f, score_sum = 0.0f;
+                    MCS sel = {}; uint32_t mc_index = MQ_NIL;
+#pragma nounroll
+                    for (int i = 0; i < K; i++) {
+                        const bool adapt = xorshift(v.rng) < P.mc_samples_adaptive_prob;
+                        uint32_t bi, h16;
+                        if (adapt) mc_adaptive_buffer_index(P, U, v.rng, cur_pos, nrm, bi, h16);
+                        else mc_static_buffer_index(P, v.rng, cur_pos, bi, h16);
+                        MCS st = mc_load(F.mc, bi);
+                        if (COUNT) ctr.mc_reads++;
+                        mc_finalize_load(U, st, h16, false, cur_pos, nrm); // volume lookups skip the below-surface test (mc.glsl:123-128)
+                        score_sum += st.sum_w;
+                        f3 d = mc_state_dir(st, cur_pos); float kk = mc_state_kappa(P, st, cur_pos);
+                        float* li = lobes + (6 * i) * 64;
+                        const float nm = vmf_norm(kk);
+                        if (xorshift(v.rng) < st.sum_w / score_sum) {
+                            sel = st; mc_index = bi;
+                            if (i > 0) { li[0] = lobes[0]; li[64] = lobes[64]; li[128] = lobes[128]; li[192] = lobes[192]; li[256] = lobes[256]; li[320] = lobes[320]; }
+                            lobes[0] = st.sum_w; lobes[64] = d.x; lobes[128] = d.y; lobes[192] = d.z; lobes[256] = kk; lobes[320] = nm;
+                        } else { li[0] = st.sum_w; li[64] = d.x; li[128] = d.y; li[192] = d.z; li[256] = kk; li[320] = nm; }
+                    }
+                    f3 wo;
+                    if (score_sum == 0.0f || xorshift(v.rng) < P.volume_phase_p) {
+                        float x0 = xorshift(v.rng), x1 = xorshift(v.rng);
+                        wo = draine_sample(x0, x1, first_wi, P.draine_g, P.draine_a);
+                        sel = mc_state_new(v.rng);
+                        mc_index = MQ_NIL;
+                    } else {
+                        float x0 = xorshift(v.rng), x1 = xorshift(v.rng);
+                        wo = vmf_sample(F3(lobes[64], lobes[128], lobes[192]), lobes[256], x0, x1);
+                    }
+                    if (score_sum > 0.0f) {
+#pragma nounroll
+                        for (int i = 0; i < K; i++) {
+                            const float* li = lobes + (6 * i) * 64;
+                            wo_p += li[0] * vmf_pdf_normed(wo, F3(li[64], li[128], li[192]), li[256], li[320]);
+                        }
+                        wo_p /= score_sum;
+                    }
+                    wo_p = (score_sum > 0.0f ? P.volume_phase_p : 1.0f) * draine_eval(dot(first_wi, wo), P.draine_g, P.draine_a) + (1.0f - P.volume_phase_p) * wo_p;
+                    v.t = t; v.pd = pd * wo_p; v.wo = wo; v.wo_p = wo_p; v.score_sum = score_sum; v.dist_score_sum = dist_score_sum; v.ds = dstate;
+                    v.mc_index = mc_index; v.mc_id = sel.id; v.mc_sum_w = sel.sum_w;
+                    v.lm_dir_ok = false;
+                    if (mc_index != MQ_NIL) v.lm_dir_ok = !(dot(wo, mc_state_dir(sel, cur_pos)) < 0.9f + 0.1f * mc_state_mean_cos(P, sel, cur_pos));
+                    cont = true;
+                }
+                store_vpath(F.paths + 10 * (size_t)my, v);
+            }
+        }
+        uint32_t q = queue_append(F, round, cont);
+        if (cont) {
+            f3 ro = cam_pos(U) + first_wi * v.t;
+            float4* r = F.rays + 2 * (size_t)q;
+            r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+            r[1] = make_float4(v.wo.x, v.wo.y, v.wo.z, 0.0f);
+            F.queue_slots[round & 1][q] = my;
+        }
+    }
+    if (COUNT) flush_counters(F.counters, ctr);
+}
+
+// the scattered ray returned: contribution + learning (volume.comp:181-230)
+template <bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel(MqSceneDev sc, MqParams P, MqFrame F, int smp, int round) {
+    const mq_uniform& U = F.u;
+    const float Wf = (float)F.W, Hf = (float)F.H;
+    const uint32_t n = F.ctrl[MQ_CTRL_QUEUE0 + round];
+    const uint32_t grid_max_x = F.W / (uint32_t)P.distance_mc_grid_width + 1u;
+    const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
+    const f3 mu_s = F3(U.prev_cam_x[3], U.prev_cam_w[3], U.prev_cam_u[3]);
+    const float mu_t = U.cam_x[3];
+    Ctr ctr = {};
+    for (uint32_t q = blockIdx.x * MQ_BLOCK + threadIdx.x; q < n; q += gridDim.x * MQ_BLOCK) {
+        const uint32_t slot = F.queue_slots[round & 1][q];
+        VPath v;
+        load_vpath(F.paths + 10 * (size_t)slot, v);
+        const size_t pidx = (size_t)v.py * F.W + v.px;
+        const f3 first_wi = camera_ray_dir((float)v.px, (float)v.py, Wf, Hf, F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]), P.fov_tan_alpha_half);
+        const f3 cur_pos = cam_pos(U) + first_wi * v.t;
+        uint4 hq = F.ray_hits[q];
+        RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
+        Hit next; next.wi = v.wo; next.pos = cur_pos; next.prev_pos = cur_pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
+        f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
+        shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
+        if (P.volume_use_light_cache && !(incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f)) { // :188-192
+            incident = rh3(throughput * light_cache_get(P, U, F.lc, v.rng, next.pos, next.normal));
+            if (COUNT) ctr.lc++;
+        }
+        const float phase = draine_eval(dot(first_wi, v.wo), P.draine_g, P.draine_a);
+        const float tr = transmittance(v.t, mu_t, P.volume_max_t);
+        f3 contrib = ((incident * phase) * mu_s) * (tr / v.pd); // :195
+        if (mfinite(contrib.x) && mfinite(contrib.y) && mfinite(contrib.z)) {
+            v.irr = v.irr + contrib;
+            float l = luminance(contrib);
+            v.m2 += l * l;
+            distance_add_sample(v.ds, v.t, l); // :202
+            if (smp == P.volume_spp - 1) {
+                uint4 gb = *(const uint4*)(F.gbuffer + 4 * pidx);
+                F.volume_depth[pidx] = f2h(v.ds.sum_w > 0.0f ? v.ds.m0 / v.ds.sum_w : __uint_as_float(gb.y));
+            }
+            if (xorshift(v.rng) < l / (v.dist_score_sum / (float)P.distance_mc_samples)) // :213
+                F.dist_mc[distance_mc_index(P, F, v.rng, (float)v.px, (float)v.py, grid_max_x)] = make_float4(v.ds.sum_w, __uint_as_float(v.ds.N), v.ds.m0, v.ds.m1);
+            const float mc_f = luminance((incident * phase) * (1.0f / v.wo_p)); // :218
+            if (xorshift(v.rng) < mc_f / (v.score_sum / (float)P.mc_samples)) {
+                float x0 = xorshift(v.rng), x1 = xorshift(v.rng);
+                f3 jn = sample_cos_frame(-first_wi, x0, x1);
+                f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
+                enqueue_update(P, F, v.rng, v.mc_index, v.mc_id, cur_pos, mc_f, next.pos, mv, jn, ctr);
+            } else if (P.mc_fast_recovery && v.mc_index != MQ_NIL && !(mc_f > 1e-3f * v.mc_sum_w) && v.lm_dir_ok) {
+                F.mc[v.mc_index].sum_w = 0.0f; // :228
+            }
+        }
+        store_vpath(F.paths + 10 * (size_t)slot, v);
+    }
+    if (COUNT) flush_counters(F.counters, ctr);
+}
+
+__global__ void mq_volume_finish_kernel(MqParams P, MqFrame F) { // volume.comp:237
+    const uint32_t total = F.n_local_tiles * 64u;
+    const float inv = 1.0f / (float)(P.volume_spp > 1 ? P.volume_spp : 1);
+    for (uint32_t my = blockIdx.x * blockDim.x + threadIdx.x; my < total; my += gridDim.x * blockDim.x) {
+        uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+        uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
+        if (px >= F.W || py >= F.H) continue;
+        uint4 a = F.paths[10 * (size_t)my];
+        *(float4*)(F.volume + 4 * ((size_t)py * F.W + px)) = make_float4(__uint_as_float(a.x) * inv, __uint_as_float(a.y) * inv, __uint_as_float(a.z) * inv, __uint_as_float(a.w) * inv);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1086,6 +1373,7 @@ __global__ void mq_clear_kernel(MqFrame F) { // clear.comp:15-23, gbuffer.comp:8
         *(uint2*)(F.gb_irr + 4 * i) = make_uint2(0, 0);
         *(uint32_t*)(F.gb_mv + 2 * i) = 0;
         *(uint4*)(F.gbuffer + 4 * i) = make_uint4(0, 0, 0, 0);
+        *(float4*)(F.volume + 4 * i) = make_float4(0, 0, 0, 0);
     }
     size_t nt = (size_t)F.n_local_tiles * 64;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (size_t)gridDim.x * blockDim.x)
@@ -1143,6 +1431,9 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
     case 13: { f3 fwd = F3(a[4], a[5], a[6]), up = F3(a[7], a[8], a[9]);
         f3 d = camera_ray_dir(a[0], a[1], a[2], a[3], up, fwd, a[10]); o[0] = d.x; o[1] = d.y; o[2] = d.z;
         camera_pixel(d, a[2], a[3], up, fwd, a[10], o[3], o[4]); break; }
+    case 14: { f3 wi = F3(a[0], a[1], a[2]); f3 w = draine_sample(a[5], a[6], wi, a[3], a[4]); o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = draine_eval(dot(wi, w), a[3], a[4]); break; }
+    case 15: { float xm = transmittance_xi_max(a[1], a[0]); o[0] = transmittance_sample2(a[0], a[2], xm); o[1] = transmittance_pdf2(o[0], a[0], xm);
+        o[2] = sample_normal_box_muller(a[3], a[4], a[5], a[6]); o[3] = sample_normal_pdf(a[3], a[4], o[2]); break; }
     }
 }
 
@@ -1182,6 +1473,22 @@ int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, ui
 }
 int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int no, const float* in, float* out, uint32_t n, hipStream_t s) {
     mq_math_kernel<<<(n + 255) / 256, 256, 0, s>>>(sc, P, op, ni, no, in, out, n);
+    return (int)hipGetLastError();
+}
+int mq_launch_forward_project(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
+    mq_forward_project_kernel<<<grid, 256, 0, s>>>(P, F);
+    return (int)hipGetLastError();
+}
+int mq_launch_volume_sample(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s) {
+    if (count) mq_volume_sample_kernel<true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, smp, round); else mq_volume_sample_kernel<false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, smp, round);
+    return (int)hipGetLastError();
+}
+int mq_launch_volume_shade(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s) {
+    if (count) mq_volume_shade_kernel<true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, smp, round); else mq_volume_shade_kernel<false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, smp, round);
+    return (int)hipGetLastError();
+}
+int mq_launch_volume_finish(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
+    mq_volume_finish_kernel<<<grid, 256, 0, s>>>(P, F);
     return (int)hipGetLastError();
 }
 int mq_render_block_size() { return MQ_BLOCK; }

@@ -204,6 +204,8 @@ bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string
     int G; float q; float outdoor_frac; float sun_k; float mu_t = 0.0f;
     if (!strcmp(name, "synth_start")) { G = 4; q = 32.0f; outdoor_frac = 0.0f; sun_k = 0.0f; }
     else if (!strcmp(name, "synth_tiny")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; }
+    else if (!strcmp(name, "synth_tiny_fog")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; mu_t = 2e-3f; }
+    else if (!strcmp(name, "synth_start_fog")) { G = 4; q = 32.0f; outdoor_frac = 0.2f; sun_k = 4.0f; mu_t = 2e-3f; }
     else if (!strcmp(name, "synth_sepulcher")) { G = 8; q = 16.0f; outdoor_frac = 0.4f; sun_k = 4.0f; }
     else if (!strcmp(name, "synth_tears")) { G = 8; q = 16.0f; outdoor_frac = 0.4f; sun_k = 6.0f; mu_t = 2e-3f; }
     else if (!strcmp(name, "synth_azad")) { G = 11; q = 16.0f; outdoor_frac = 0.5f; sun_k = 4.0f; }

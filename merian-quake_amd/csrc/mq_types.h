@@ -120,6 +120,7 @@ struct MqParams {
     uint32_t distance_mc_vertex_state_count, seed;
     int32_t gbuffer_hide_sun, quirk_lc_max_wo_p, quirk_n16_wrap;
     int32_t debug_output_selector;
+    int32_t volume_forward_project;
     // derived on the host with the same float operations the kernels would use (mq_api.cpp props_to_params)
     float mc_static_inv_width;
     float mc_inv_width_lut[MQ_WIDTH_LUT]; // 1 / width(level) of the adaptive MC grid
@@ -143,6 +144,9 @@ struct MqSceneDev {
     uint32_t n_nodes, n_tris;
 };
 
+// 16-byte distance Markov-chain state, grid.h:48-52
+struct MqDistMC { float sum_w; uint32_t N; float m0, m1; };
+
 struct MqCountersDev {
     unsigned long long rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels, lc_ok, lc_cancel, q_rays, q_nodes, q_tris, q_paths;
@@ -163,6 +167,12 @@ struct MqFrame {
     uint16_t* gb_mv;       // W*H*2 half
     uint32_t* gbuffer;     // W*H*4 dwords
     uint32_t* hits;        // W*H*10 dwords
+    float* volume;         // W*H*4 (volume.comp:237)
+    uint16_t* volume_depth;      // W*H half (volume.comp:211)
+    uint16_t* prev_volume_depth; // W*H half: last frame's volume_depth (delay-1 feedback)
+    uint16_t* volume_mv;   // W*H*2 half
+    float4* dist_mc;       // distance Markov chains: (sum_w, N, m0, m1) per state, 10 states per grid vertex
+    uint32_t dist_mc_n;
     // learning state
     MqMCState* mc;
     MqLCCell* lc;

@@ -18,7 +18,8 @@ MQ_MAX_GLTEXTURES = 4096
 MQ_MAX_GEOMETRIES = 16
 MQ_GEO_OPAQUE, MQ_GEO_STATIC = 1, 2
 MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
-(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_COUNT) = range(8)
+(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_VOLUME, OUT_VOLUME_DEPTH,
+ OUT_VOLUME_MV, OUT_COUNT) = range(11)
 MQ_ENODEVICE = -2
 
 EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),
@@ -48,7 +49,7 @@ class Constants(C.Structure):
 class IoDesc(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bytes", C.c_size_t * OUT_COUNT),
                 ("bytes_per_pixel", C.c_uint32 * OUT_COUNT), ("state_bytes_markovchain", C.c_size_t),
-                ("state_bytes_lightcache", C.c_size_t), ("state_bytes_update_queue", C.c_size_t)]
+                ("state_bytes_lightcache", C.c_size_t), ("state_bytes_update_queue", C.c_size_t), ("state_bytes_volume_distancemc", C.c_size_t)]
 
 
 class Counters(C.Structure):
@@ -285,6 +286,9 @@ class Context:
 
     def irradiance(self):
         return self.read_output(OUT_IRRADIANCE).view(np.float32).reshape(self.H, self.W, 4)
+
+    def volume(self):
+        return self.read_output(OUT_VOLUME).view(np.float32).reshape(self.H, self.W, 4)
 
     def last_frame_ms(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()

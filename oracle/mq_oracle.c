@@ -72,6 +72,10 @@ typedef struct { v3 pos, prev_pos, wi, normal; uint32_t enc_geonormal; v3 albedo
 typedef struct { float pos[3]; uint16_t mv[3]; uint16_t _pad; uint32_t wi, normal, enc_geonormal; uint16_t albedo[3]; uint16_t roughness; } chit_t;
 
 typedef struct { uint32_t enc_normal; float linear_z; uint16_t grad_z[2]; float vel_z; } gbuf_t;
+/* grid.h:48-52 */
+typedef struct { float sum_w; uint32_t N; float m0, m1; } distmc_t;
+#define DISTANCE_ML_MAX_N 1024 /* mc_distance.glsl:2 */
+#define DISTANCE_ML_MIN_ALPHA 0.01f
 
 struct orc_ctx {
     orc_params_t p;
@@ -91,6 +95,10 @@ struct orc_ctx {
     uint32_t* upd_touched; uint32_t upd_touched_n;
     /* outputs */
     float* irradiance; uint16_t* gb_albedo; uint16_t* gb_irr; uint16_t* gb_mv; gbuf_t* gbuffer; chit_t* hits;
+    /* volume pass (volume.comp, mc_distance.glsl, volume_forward_project.comp) */
+    float* volume; uint16_t* volume_depth; uint16_t* prev_volume_depth; uint16_t* volume_mv;
+    distmc_t* dist_mc; uint32_t dist_mc_n;
+    uint64_t iteration;
     orc_counters_t ctr;
     int racy; /* threads > 1 in guided mode */
 };
@@ -112,7 +120,7 @@ void orc_params_header_defaults(orc_params_t* p) { /* render_mcpg.hpp:108-166, g
     p->volume_max_t = 1000.0f; p->surf_bsdf_p = 0.15f; p->volume_phase_p = 0.3f; p->dir_guide_prior = 0.2f; p->dist_guide_p = 0.0f;
     p->distance_mc_vertex_state_count = 10; p->seed = 0;
     { double d = 25.0; p->draine_g = (float)exp(-2.20679 / (d + 3.91029) - 0.428934); p->draine_a = (float)exp(3.62489 - 8.29288 / (d + 5.52825)); }
-    p->gbuffer_hide_sun = 1; p->quirk_lc_max_wo_p = 1; p->quirk_n16_wrap = 0;
+    p->gbuffer_hide_sun = 1; p->quirk_lc_max_wo_p = 1; p->quirk_n16_wrap = 0; p->volume_forward_project = 1;
 }
 void orc_params_json_defaults(orc_params_t* p) { /* default_config.json:599-638 */
     orc_params_header_defaults(p);
@@ -140,6 +148,8 @@ orc_ctx* orc_create(const orc_params_t* p) {
 static void free_state(orc_ctx* c) {
     free(c->mc); free(c->lc); free(c->upd_count); free(c->upd_rec); free(c->upd_pool); free(c->upd_touched);
     free(c->irradiance); free(c->gb_albedo); free(c->gb_irr); free(c->gb_mv); free(c->gbuffer); free(c->hits);
+    free(c->volume); free(c->volume_depth); free(c->prev_volume_depth); free(c->volume_mv); free(c->dist_mc);
+    c->volume = NULL; c->volume_depth = c->prev_volume_depth = c->volume_mv = NULL; c->dist_mc = NULL;
     c->mc = NULL; c->lc = NULL; c->upd_count = c->upd_rec = NULL; c->upd_pool = NULL; c->upd_touched = NULL;
     c->irradiance = NULL; c->gb_albedo = c->gb_irr = c->gb_mv = NULL; c->gbuffer = NULL; c->hits = NULL;
 }
@@ -390,12 +400,17 @@ int orc_connect(orc_ctx* c, uint32_t w, uint32_t h) {
     c->upd_count = (uint32_t*)calloc(c->mc_total, 4);
     c->upd_rec = (uint32_t*)calloc(c->mc_total, 4);
     size_t segs = px * (size_t)(c->p.spp > 0 ? c->p.spp : 1) * (size_t)(c->p.max_path_length > 1 ? c->p.max_path_length - 1 : 1);
+    segs += px * (size_t)(c->p.volume_spp > 0 ? c->p.volume_spp : 0); /* the volume pass queues updates too */
     c->upd_pool_cap = (uint32_t)(segs < c->mc_total ? segs : c->mc_total);
     c->upd_pool = (mcupdate_t*)calloc(c->upd_pool_cap ? c->upd_pool_cap : 1, sizeof(mcupdate_t));
     c->upd_touched = (uint32_t*)calloc(c->upd_pool_cap ? c->upd_pool_cap : 1, 4);
     c->irradiance = (float*)calloc(px, 16);
     c->gb_albedo = (uint16_t*)calloc(px, 8); c->gb_irr = (uint16_t*)calloc(px, 8); c->gb_mv = (uint16_t*)calloc(px, 4);
     c->gbuffer = (gbuf_t*)calloc(px, sizeof(gbuf_t)); c->hits = (chit_t*)calloc(px, sizeof(chit_t));
+    c->volume = (float*)calloc(px, 16); c->volume_depth = (uint16_t*)calloc(px, 2); c->prev_volume_depth = (uint16_t*)calloc(px, 2); c->volume_mv = (uint16_t*)calloc(px, 4);
+    { uint32_t gw = c->p.distance_mc_grid_width > 0 ? (uint32_t)c->p.distance_mc_grid_width : 25u; /* render_mcpg.cpp:80-82 */
+      c->dist_mc_n = (w / gw + 2) * (h / gw + 2) * 10u; c->dist_mc = (distmc_t*)calloc(c->dist_mc_n, sizeof(distmc_t)); }
+    c->iteration = 0;
     if (!c->mc || !c->lc || !c->upd_count || !c->upd_rec || !c->upd_pool || !c->irradiance || !c->hits) return -1;
     return 0;
 }
@@ -409,6 +424,9 @@ const void* orc_output(orc_ctx* c, int which, size_t* bytes) {
     case ORC_OUT_GB_MV: if (bytes) *bytes = px * 4; return c->gb_mv;
     case ORC_OUT_GBUFFER: if (bytes) *bytes = px * sizeof(gbuf_t); return c->gbuffer;
     case ORC_OUT_HITS: if (bytes) *bytes = px * sizeof(chit_t); return c->hits;
+    case ORC_OUT_VOLUME: if (bytes) *bytes = px * 16; return c->volume;
+    case ORC_OUT_VOLUME_DEPTH: if (bytes) *bytes = px * 2; return c->volume_depth;
+    case ORC_OUT_VOLUME_MV: if (bytes) *bytes = px * 4; return c->volume_mv;
     }
     return NULL;
 }
@@ -907,6 +925,186 @@ static void apply_slot(tls_t* tl, uint32_t slot) {
 }
 static int cmp_u32(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
 
+
+/* ---------------------------------------------------------------- volume pass */
+
+/* mc_distance.glsl:10-16 */
+static void distance_normal_dist(const distmc_t* s, float* mu, float* sigma) {
+    float den = s->sum_w > 0.0f ? s->sum_w : 1.0f;
+    float m0 = s->m0 / den, m1 = s->m1 / den;
+    float sg = sqrtf(omax(m1 - m0 * m0, 0.0f));
+    float n2 = (float)(s->N * s->N);
+    *mu = m0; *sigma = (n2 * sg + 0.2f) / (n2 + 0.2f);
+}
+/* mc_distance.glsl:19-27 */
+static void distance_add_sample(distmc_t* s, float dist, float w) {
+    s->N = s->N + 1 < DISTANCE_ML_MAX_N ? s->N + 1 : DISTANCE_ML_MAX_N;
+    float alpha = omax(1.0f / (float)s->N, DISTANCE_ML_MIN_ALPHA);
+    s->sum_w = omix(s->sum_w, w, alpha);
+    s->m0 = omix(s->m0, w * dist, alpha); s->m1 = omix(s->m1, w * (dist * dist), alpha);
+}
+/* mc_distance.glsl:29-44: address of a random state of the stochastically chosen grid vertex */
+static uint32_t distance_mc_index(tls_t* tl, float px, float py, uint32_t grid_max_x) {
+    const orc_params_t* p = &tl->c->p;
+    float inv = 1.0f / (float)p->distance_mc_grid_width;
+    float xi = X(tl);
+    int gx = (int)floorf(px * inv + xi), gy = (int)floorf(py * inv + xi);
+    uint32_t st = (uint32_t)(X(tl) * (float)p->distance_mc_vertex_state_count);
+    uint32_t v = (uint32_t)gx + (grid_max_x + 1u) * (uint32_t)gy;
+    uint32_t idx = v * 10u + st; /* MAX_DISTANCE_MC_VERTEX_STATE_COUNT states per vertex (config.h:22) */
+    return idx < tl->c->dist_mc_n ? idx : tl->c->dist_mc_n - 1;
+}
+
+/* volume_forward_project.comp:17-53 */
+static void forward_project_pixel(orc_ctx* c, uint32_t px, uint32_t py) {
+    const orc_uniform_t* u = &c->u;
+    float W = (float)c->W, H = (float)c->H, th = c->p.fov_tan_alpha_half;
+    float prev_depth = orc_h2f(c->prev_volume_depth[(size_t)py * c->W + px]);
+    v3 pwi = orc_camera_ray_dir((float)px, (float)py, W, H, V3(u->prev_cam_u[0], u->prev_cam_u[1], u->prev_cam_u[2]), V3(u->prev_cam_w[0], u->prev_cam_w[1], u->prev_cam_w[2]), th);
+    v3 ppos = vadd(V3(u->prev_cam_x[0], u->prev_cam_x[1], u->prev_cam_x[2]), vscale(pwi, prev_depth));
+    float fx, fy;
+    orc_camera_pixel(vsub(ppos, cam_x(c)), W, H, V3(u->cam_u[0], u->cam_u[1], u->cam_u[2]), V3(u->cam_w[0], u->cam_w[1], u->cam_w[2]), th, &fx, &fy);
+    float rx = floorf(fx + 0.5f), ry = floorf(fy + 0.5f);
+    if (!(rx >= 0.0f && ry >= 0.0f && rx < W && ry < H)) return;
+    if (prev_depth < 50.0f) return;
+    int nx = (int)rx, ny = (int)ry;
+    size_t o = 2 * ((size_t)ny * c->W + (size_t)nx);
+    c->volume_mv[o] = orc_f2h((float)px - rx); c->volume_mv[o + 1] = orc_f2h((float)py - ry);
+}
+
+/* volume.comp:34-238 */
+static void volume_pixel(tls_t* tl, uint32_t px, uint32_t py) {
+    orc_ctx* c = (orc_ctx*)tl->c;
+    const orc_params_t* p = &c->p;
+    const orc_uniform_t* u = &c->u;
+    size_t idx = (size_t)py * c->W + px;
+    const uint32_t grid_max_x = c->W / (uint32_t)p->distance_mc_grid_width + 1u;
+    const float mu_t = u->cam_x[3];
+    const v3 mu_s = V3(u->prev_cam_x[3], u->prev_cam_w[3], u->prev_cam_u[3]);
+    tl->rng = orc_pcg4d16(px, py, u->frame, p->seed);
+    v3 irr = V3(0, 0, 0); float second_moment = 0.0f;
+    const gbuf_t* gb = &c->gbuffer[idx];
+    const float linear_z = gb->linear_z;
+    const v3 first_n = orc_decode_normal(gb->enc_normal);
+    const v3 first_wi = orc_camera_ray_dir((float)px, (float)py, (float)c->W, (float)c->H, V3(u->cam_u[0], u->cam_u[1], u->cam_u[2]), V3(u->cam_w[0], u->cam_w[1], u->cam_w[2]), p->fov_tan_alpha_half);
+    const float mvx = orc_h2f(c->volume_mv[2 * idx]), mvy = orc_h2f(c->volume_mv[2 * idx + 1]);
+    const v3 sun = V3(p->sun_color[0], p->sun_color[1], p->sun_color[2]);
+    int KD = p->distance_mc_samples < MAX_MC_SAMPLES ? p->distance_mc_samples : MAX_MC_SAMPLES;
+    int K = p->mc_samples < MAX_MC_SAMPLES ? p->mc_samples : MAX_MC_SAMPLES;
+    const float tmax_v = omin(linear_z, p->volume_max_t);
+    if (mu_t > 0.0f)
+    for (int s = 0; s < p->volume_spp; s++) {
+        float pd = 0.0f, t = 0.0f;
+        distmc_t dstate; memset(&dstate, 0, sizeof dstate);
+        float dist_score_sum = 0.0f;
+        { /* camera-distance sampling, :58-104 */
+            const float xi_max = orc_transmittance_xi_max(tmax_v, mu_t);
+            float scores[MAX_MC_SAMPLES] = {0}, nmu[MAX_MC_SAMPLES] = {0}, nsg[MAX_MC_SAMPLES] = {0};
+            for (int i = 0; i < KD; i++) {
+                distmc_t st;
+                if (s == 0) {
+                    float qx = oclamp((float)px + mvx, 0.0f, (float)c->W - 1.0f), qy = oclamp((float)py + mvy, 0.0f, (float)c->H - 1.0f);
+                    st = c->dist_mc[distance_mc_index(tl, qx, qy, grid_max_x)];
+                    distance_normal_dist(&st, &nmu[i], &nsg[i]);
+                    nmu[i] -= vdot(vsub(cam_x(c), V3(u->prev_cam_x[0], u->prev_cam_x[1], u->prev_cam_x[2])), first_wi);
+                } else {
+                    st = c->dist_mc[distance_mc_index(tl, (float)px, (float)py, grid_max_x)];
+                    distance_normal_dist(&st, &nmu[i], &nsg[i]);
+                }
+                scores[i] = st.sum_w * (st.sum_w > 0.0f ? 1.0f : 0.0f) * (nmu[i] < linear_z ? 1.0f : 0.0f);
+                dist_score_sum += scores[i];
+                if (X(tl) < scores[i] / dist_score_sum) {
+                    dstate = st;
+                    float x0 = X(tl), x1 = X(tl);
+                    t = orc_sample_normal_box_muller(nmu[i], nsg[i], x0, x1);
+                }
+            }
+            if (p->dist_guide_p < X(tl) || dist_score_sum == 0.0f) t = orc_transmittance_sample2(mu_t, X(tl), xi_max);
+            else if (t >= tmax_v || t <= 0.0f) continue;
+            if (dist_score_sum > 0.0f) {
+                for (int i = 0; i < KD; i++) pd += scores[i] * orc_sample_normal_pdf(nmu[i], nsg[i], t);
+                pd /= dist_score_sum;
+            }
+            pd = (dist_score_sum > 0.0f ? (1.0f - p->dist_guide_p) : 1.0f) * orc_transmittance_pdf2(t, mu_t, xi_max) + p->dist_guide_p * pd;
+        }
+        v3 cur_pos = vadd(cam_x(c), vscale(first_wi, t)); /* :109 */
+        v3 cur_normal = first_n;                          /* :111 (unused by the lookups below, kept for clarity) */
+        (void)cur_normal;
+        v3 wo; float wo_p = 0.0f, score_sum = 0.0f;
+        mcstate_t mc_state; memset(&mc_state, 0, sizeof mc_state);
+        uint32_t mc_buffer_index = 0xffffffffu;
+        { /* :119-177 */
+            float scores[MAX_MC_SAMPLES] = {0}, vk[MAX_MC_SAMPLES] = {0}; v3 vdir[MAX_MC_SAMPLES]; memset(vdir, 0, sizeof vdir);
+            for (int i = 0; i < K; i++) {
+                int adaptive = X(tl) < p->mc_samples_adaptive_prob;
+                uint32_t bi; uint16_t hash;
+                if (adaptive) mc_adaptive_buffer_index(tl, cur_pos, vneg(first_wi), &bi, &hash);
+                else mc_static_buffer_index(tl, cur_pos, &bi, &hash);
+                mcstate_t st = c->mc[bi];
+                tl->ctr.mc_state_reads++;
+                { /* mc_adaptive_finalize_load / two-argument mc_static_finalize_load, mc.glsl:90-96,123-128 */
+                    if (st.sum_w < 0.0f || hash != st.hash) st.sum_w = 0.0f;
+                    float k = st.sum_w * (u->cl_time - st.T);
+                    st.w_tgt = vadd(st.w_tgt, vscale(h3(st.mv), k));
+                }
+                score_sum += st.sum_w;
+                v3 d = mc_state_dir(&st, cur_pos); float kk = mc_state_kappa(p, &st, cur_pos);
+                if (X(tl) < st.sum_w / score_sum) {
+                    mc_state = st; mc_buffer_index = bi;
+                    vdir[i] = vdir[0]; vk[i] = vk[0]; scores[i] = scores[0];
+                    scores[0] = st.sum_w; vdir[0] = d; vk[0] = kk;
+                } else { scores[i] = st.sum_w; vdir[i] = d; vk[i] = kk; }
+            }
+            if (score_sum == 0.0f || X(tl) < p->volume_phase_p) {
+                float x0 = X(tl), x1 = X(tl);
+                wo = orc_draine_sample(x0, x1, first_wi, p->draine_g, p->draine_a);
+                mc_state = mc_state_new(tl);
+                mc_buffer_index = 0xffffffffu;
+            } else {
+                float x0 = X(tl), x1 = X(tl);
+                wo = orc_vmf_sample(vdir[0], vk[0], x0, x1);
+            }
+            if (score_sum > 0.0f) {
+                for (int i = 0; i < K; i++) wo_p += scores[i] * orc_vmf_pdf(wo, vdir[i], vk[i]);
+                wo_p /= score_sum;
+            }
+            wo_p = (score_sum > 0.0f ? p->volume_phase_p : 1.0f) * orc_draine_eval(vdot(first_wi, wo), p->draine_g, p->draine_a) + (1.0f - p->volume_phase_p) * wo_p;
+        }
+        pd *= wo_p;
+        hit_t next; memset(&next, 0, sizeof next);
+        next.wi = wo; next.pos = cur_pos;
+        v3 incident = V3(0, 0, 0), throughput = V3(1, 1, 1);
+        trace_ray(tl, &throughput, &incident, &next, sun);
+        if (p->volume_use_light_cache && !(incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f))
+            incident = orc_rh3(vmul(throughput, light_cache_get(tl, next.pos, next.normal))); /* :188-192 */
+        const float phase = orc_draine_eval(vdot(first_wi, wo), p->draine_g, p->draine_a);
+        const float tr = orc_transmittance(t, mu_t, p->volume_max_t);
+        v3 contrib = vscale(vmul(vscale(incident, phase), mu_s), tr / pd); /* :195 */
+        if (finite3(contrib)) {
+            irr = vadd(irr, contrib);
+            float l = orc_luminance(contrib);
+            second_moment += l * l;
+            distance_add_sample(&dstate, t, l); /* :202 */
+            if (s == p->volume_spp - 1) c->volume_depth[idx] = orc_f2h(dstate.sum_w > 0.0f ? dstate.m0 / dstate.sum_w : linear_z);
+            if (X(tl) < l / (dist_score_sum / (float)p->distance_mc_samples)) { /* :213 */
+                c->dist_mc[distance_mc_index(tl, (float)px, (float)py, grid_max_x)] = dstate;
+            }
+            const float mc_f = orc_luminance(vscale(vscale(incident, phase), 1.0f / wo_p)); /* :218 */
+            if (X(tl) < mc_f / (score_sum / (float)p->mc_samples)) {
+                float x0 = X(tl), x1 = X(tl);
+                v3 jn = orc_sample_cos_frame(vneg(first_wi), x0, x1);
+                v3 mv = orc_rh3(vscale(vsub(next.pos, next.prev_pos), 1.0f / u->cam_w[3]));
+                mc_state_add_sample(tl, &mc_state, cur_pos, mc_f, next.pos, mv, jn, mc_buffer_index);
+            } else if (p->mc_fast_recovery && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur_pos)) {
+                c->mc[mc_buffer_index].sum_w = 0.0f;
+            }
+        }
+    }
+    float inv = 1.0f / (float)(p->volume_spp > 1 ? p->volume_spp : 1);
+    float* o = c->volume + 4 * idx;
+    o[0] = irr.x * inv; o[1] = irr.y * inv; o[2] = irr.z * inv; o[3] = second_moment * inv;
+}
+
 /* ---------------------------------------------------------------- frame driver */
 
 typedef struct { orc_ctx* c; int tid, nthreads, pass; orc_counters_t ctr; } job_t;
@@ -914,7 +1112,7 @@ static void* worker(void* arg) {
     job_t* j = (job_t*)arg; orc_ctx* c = j->c;
     tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
     for (uint32_t y = (uint32_t)j->tid; y < c->H; y += (uint32_t)j->nthreads)
-        for (uint32_t x = 0; x < c->W; x++) { if (j->pass == 0) gbuffer_pixel(&tl, x, y); else mcpg_pixel(&tl, x, y); }
+        for (uint32_t x = 0; x < c->W; x++) { if (j->pass == 0) gbuffer_pixel(&tl, x, y); else if (j->pass == 1) mcpg_pixel(&tl, x, y); else volume_pixel(&tl, x, y); }
     j->ctr = tl.ctr;
     return NULL;
 }
@@ -937,7 +1135,7 @@ int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
     size_t px = (size_t)c->W * c->H;
     if (!render) { /* clear.comp:15-23, gbuffer.comp:83-90 */
         memset(c->irradiance, 0, px * 16); memset(c->gb_albedo, 0, px * 8); memset(c->gb_irr, 0, px * 8); memset(c->gb_mv, 0, px * 4);
-        memset(c->gbuffer, 0, px * sizeof(gbuf_t));
+        memset(c->gbuffer, 0, px * sizeof(gbuf_t)); memset(c->volume, 0, px * 16);
         return 0;
     }
     run_pass(c, 0, threads);
@@ -949,6 +1147,17 @@ int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
     for (uint32_t i = 0; i < n; i++) apply_slot(&tl, c->upd_touched[i]);
     acc_ctr(&c->ctr, &tl.ctr);
     c->upd_pool_used = 0;
+    /* volume passes, render_mcpg.cpp:280-320: copy mv, forward-project, single-scatter estimator.
+     * Its Markov-chain updates stay queued until the next frame's update pass. */
+    if (c->p.volume_spp > 0) {
+        memcpy(c->prev_volume_depth, c->volume_depth, px * 2); /* delay-1 feedback connector, default_config.json:243-248 */
+        memcpy(c->volume_mv, c->gb_mv, px * 4);
+        if (c->p.volume_forward_project && c->iteration != 0)
+            for (uint32_t y = 0; y < c->H; y++) for (uint32_t x = 0; x < c->W; x++) forward_project_pixel(c, x, y);
+        run_pass(c, 2, threads);
+        /* keep the touched-slot list of the volume pass for the next frame's update pass */
+    } else memset(c->volume, 0, px * 16);
+    c->iteration++;
     return 0;
 }
 
@@ -966,7 +1175,7 @@ int orc_trace_rays(orc_ctx* c, const float* org, const float* dir, uint32_t n, u
     return 0;
 }
 
-static const int k_arity[ORC_OP_COUNT][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}};
+static const int k_arity[ORC_OP_COUNT][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}};
 int orc_op_arity(int op, int* n_in, int* n_out) {
     if (op < 0 || op >= ORC_OP_COUNT) return -1;
     *n_in = k_arity[op][0]; *n_out = k_arity[op][1];
@@ -999,6 +1208,10 @@ int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n) {
         case ORC_OP_CAMERA: { v3 fwd = V3(a[4], a[5], a[6]), up = V3(a[7], a[8], a[9]);
             v3 d = orc_camera_ray_dir(a[0], a[1], a[2], a[3], up, fwd, a[10]); o[0] = d.x; o[1] = d.y; o[2] = d.z;
             orc_camera_pixel(d, a[2], a[3], up, fwd, a[10], &o[3], &o[4]); break; }
+        case ORC_OP_DRAINE: { v3 wi = V3(a[0], a[1], a[2]); v3 w = orc_draine_sample(a[5], a[6], wi, a[3], a[4]);
+            o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = orc_draine_eval(vdot(wi, w), a[3], a[4]); break; }
+        case ORC_OP_DISTANCE: { float xm = orc_transmittance_xi_max(a[1], a[0]); o[0] = orc_transmittance_sample2(a[0], a[2], xm); o[1] = orc_transmittance_pdf2(o[0], a[0], xm);
+            o[2] = orc_sample_normal_box_muller(a[3], a[4], a[5], a[6]); o[3] = orc_sample_normal_pdf(a[3], a[4], o[2]); break; }
         }
     }
     return 0;

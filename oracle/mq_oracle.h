@@ -90,6 +90,7 @@ typedef struct {
     /* named quirk switches */
     int32_t quirk_lc_max_wo_p; /* 1 = keep `max(wo_p, 10)` of mcpg.comp:170 (default) */
     int32_t quirk_n16_wrap;    /* 1 = wrap N*N to 16 bit as GLSL uint16 arithmetic would (mc.glsl:26) */
+    int32_t volume_forward_project; /* render_mcpg.hpp:153 */
 } orc_params_t;
 
 void orc_params_header_defaults(orc_params_t* p); /* src/render_mcpg/render_mcpg.hpp:108-166 */
@@ -110,6 +111,9 @@ enum {
     ORC_OUT_GB_MV = 3,           /* gbuffer: RG16F */
     ORC_OUT_GBUFFER = 4,         /* 16 B/px: enc_normal u32, linear_z f32, grad_z 2xf16, vel_z f32 */
     ORC_OUT_HITS = 5,            /* 40 B/px CompressedHit (res/shader/hit.glsl.h:19-30) */
+    ORC_OUT_VOLUME = 6,          /* mcpg "volume" RGBA32F (volume.comp:237) */
+    ORC_OUT_VOLUME_DEPTH = 7,    /* mcpg "volume_depth" R16F (volume.comp:211) */
+    ORC_OUT_VOLUME_MV = 8,       /* mcpg "volume_mv" RG16F (render_mcpg.cpp:284-311) */
     ORC_OUT_COUNT
 };
 
@@ -159,7 +163,9 @@ enum {
     ORC_OP_HASHGRID = 11,   /* pos3 normal3 level width-as-float size-punned (9) -> idx, chk punned (2) */
     ORC_OP_LDR_TO_HDR = 12, /* 3 -> 3 */
     ORC_OP_CAMERA = 13,     /* px py W H fwd3 up3 tan (11) -> dir3 + pixel2 roundtrip (5) */
-    ORC_OP_COUNT
+    ORC_OP_DRAINE = 14,     /* wi3 g a xi2 (7) -> wo3, pdf (4) */
+    ORC_OP_DISTANCE = 15,   /* mu_t tmax xi, gauss mu sigma xi2 (7) -> t, pdf_t, gauss x, gauss pdf (4) */
+    ORC_OP_COUNT = 16
 };
 int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n);
 int orc_op_arity(int op, int* n_in, int* n_out);

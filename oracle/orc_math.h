@@ -365,6 +365,70 @@ static inline v3 orc_ldr_to_hdr(v3 c) {
     return orc_rh3(V3(orc_rh(sqrtf(c.x)) * 2.0f * k, orc_rh(sqrtf(c.y)) * 2.0f * k, orc_rh(sqrtf(c.z)) * 2.0f * k));
 }
 
+/* ---- participating medium helpers (merian-shaders transmittance.glsl / phase_draine.glsl /
+ * sampling.glsl, DEFINED; used by volume.comp:34-238) ------------------------------------------- */
+static inline float orc_transmittance_xi_max(float tmax, float mu_t) { return 1.0f - orc_exp(-mu_t * tmax); }
+static inline float orc_transmittance_sample2(float mu_t, float xi, float xi_max) { return -orc_log(omax(1.0f - xi * xi_max, 1e-37f)) / mu_t; }
+static inline float orc_transmittance_pdf2(float t, float mu_t, float xi_max) { return mu_t * orc_exp(-mu_t * t) / xi_max; }
+static inline float orc_sample_normal_box_muller(float mu, float sigma, float xi0, float xi1) {
+    float r = sqrtf(-2.0f * orc_log(omax(xi0, 1e-37f)));
+    float c, sn;
+    orc_sincos2pi(xi1, &c, &sn);
+    return mu + sigma * (r * c);
+}
+static inline float orc_sample_normal_pdf(float mu, float sigma, float x) {
+    float d = (x - mu) / sigma;
+    return orc_exp(-0.5f * (d * d)) / (sigma * 2.50662827463100024f);
+}
+/* Draine phase function (Jendersie & d'Eon 2023): cos_t = dot(travel direction in, direction out) */
+static inline float orc_draine_eval(float cos_t, float g, float a) {
+    float g2 = g * g;
+    float s = 1.0f + g2 - 2.0f * g * cos_t;
+    float s32 = s * sqrtf(s);
+    return ORC_INV_4PI * ((1.0f - g2) / s32) * ((1.0f + a * (cos_t * cos_t)) / (1.0f + a * (1.0f + 2.0f * g2) / 3.0f));
+}
+/* antiderivative in mu of (1 + a mu^2) s^{-3/2}, s = 1 + g^2 - 2 g mu */
+static inline float orc_draine_F(float mu, float g, float a) {
+    float A = 1.0f + g * g;
+    float s = A - 2.0f * g * mu;
+    float rs = sqrtf(s);
+    float k = a / (4.0f * (g * g));
+    return (1.0f / g) * (1.0f / rs + k * (A * A / rs + 2.0f * A * rs - s * rs / 3.0f));
+}
+/* exact inverse-CDF sampling of cos(theta): Henyey-Greenstein start + 8 clamped Newton steps on the closed-form CDF */
+static inline float orc_draine_sample_cos(float xi, float g, float a) {
+    if (!(fabsf(g) > 1e-3f)) return 1.0f - 2.0f * xi;
+    float g2 = g * g;
+    float q = (1.0f - g2) / (1.0f - g + 2.0f * g * xi);
+    float mu = oclamp((1.0f + g2 - q * q) / (2.0f * g), -1.0f, 1.0f);
+    float F0 = orc_draine_F(-1.0f, g, a), F1 = orc_draine_F(1.0f, g, a);
+    float target = F0 + xi * (F1 - F0);
+    for (int i = 0; i < 8; i++) {
+        float s = 1.0f + g2 - 2.0f * g * mu;
+        float dF = (1.0f + a * (mu * mu)) / (s * sqrtf(s));
+        mu = oclamp(mu - (orc_draine_F(mu, g, a) - target) / dF, -1.0f, 1.0f);
+    }
+    return mu;
+}
+static inline v3 orc_draine_sample(float xi0, float xi1, v3 wi, float g, float a) {
+    float mu = orc_draine_sample_cos(xi0, g, a);
+    float sr = sqrtf(omax(1.0f - mu * mu, 0.0f));
+    float c, sn;
+    orc_sincos2pi(xi1, &c, &sn);
+    v3 t, b;
+    orc_make_frame(wi, &t, &b);
+    return vadd(vadd(vscale(t, sr * c), vscale(b, sr * sn)), vscale(wi, mu));
+}
+/* cosine-weighted hemisphere direction in the frame of n (make_frame(n) * sample_cos(xi)) */
+static inline v3 orc_sample_cos_frame(v3 n, float xi0, float xi1) {
+    float r = sqrtf(xi0), z = sqrtf(omax(1.0f - xi0, 0.0f));
+    float c, sn;
+    orc_sincos2pi(xi1, &c, &sn);
+    v3 t, b;
+    orc_make_frame(n, &t, &b);
+    return vadd(vadd(vscale(t, r * c), vscale(b, r * sn)), vscale(n, z));
+}
+
 /* ---- pinhole camera (merian-shaders/camera.glsl, DEFINED): pixel centres, +y down ------------ */
 static inline v3 orc_camera_ray_dir(float px, float py, float W, float H, v3 up, v3 fwd, float tan_half) {
     v3 right = vcross(fwd, up);

@@ -7,11 +7,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "oracle", "libmqoracle.so")
 
-(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS) = range(6)
+(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_VOLUME, OUT_VOLUME_DEPTH, OUT_VOLUME_MV) = range(9)
 (OP_EXP2, OP_LOG2, OP_SINCOS2PI, OP_POW, OP_F2H2F, OP_ENC_DEC_NORMAL, OP_BSDF_SAMPLE, OP_VMF_SAMPLE, OP_XORSHIFT,
- OP_PCG4D16, OP_SKY, OP_HASHGRID, OP_LDR_TO_HDR, OP_CAMERA) = range(14)
+ OP_PCG4D16, OP_SKY, OP_HASHGRID, OP_LDR_TO_HDR, OP_CAMERA, OP_DRAINE, OP_DISTANCE) = range(16)
 OP_ARITY = {0: (1, 1), 1: (1, 1), 2: (1, 2), 3: (2, 1), 4: (1, 1), 5: (3, 4), 6: (10, 5), 7: (6, 4), 8: (1, 4), 9: (4, 1),
-            10: (3, 3), 11: (9, 2), 12: (3, 3), 13: (11, 5)}
+            10: (3, 3), 11: (9, 2), 12: (3, 3), 13: (11, 5), 14: (7, 4), 15: (7, 4)}
 
 
 class Params(C.Structure):
@@ -29,7 +29,7 @@ class Params(C.Structure):
                 ("distance_mc_grid_width", C.c_int32), ("volume_max_t", C.c_float), ("surf_bsdf_p", C.c_float),
                 ("volume_phase_p", C.c_float), ("dir_guide_prior", C.c_float), ("dist_guide_p", C.c_float),
                 ("distance_mc_vertex_state_count", C.c_uint32), ("seed", C.c_uint32), ("gbuffer_hide_sun", C.c_int32),
-                ("quirk_lc_max_wo_p", C.c_int32), ("quirk_n16_wrap", C.c_int32)]
+                ("quirk_lc_max_wo_p", C.c_int32), ("quirk_n16_wrap", C.c_int32), ("volume_forward_project", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -134,6 +134,9 @@ class Oracle:
     def irradiance(self):
         return self.output(OUT_IRRADIANCE).view(np.float32).reshape(self.H, self.W, 4)
 
+    def volume(self):
+        return self.output(OUT_VOLUME).view(np.float32).reshape(self.H, self.W, 4)
+
     def counters(self, reset=False):
         c = Counters()
         self.l.orc_get_counters(self.h, C.byref(c), 1 if reset else 0)
@@ -171,6 +174,13 @@ def params_from_ctx(ctx, constants=None):
     p.mc_adaptive_grid_steps_per_unit_size = g("adaptive grid steps per unit")
     p.mc_static_buffer_size = int(g("static grid buf size")); p.mc_static_grid_width = g("mc static width")
     p.surf_bsdf_p = g("BSDF Prob"); p.dir_guide_prior = g("ML Prior"); p.seed = int(g("seed"))
+    p.volume_spp = int(g("volume spp")); p.volume_use_light_cache = int(g("volume: use LC")); p.distance_mc_samples = int(g("dist mc samples"))
+    p.distance_mc_grid_width = int(g("dist mc grid width")); p.distance_mc_vertex_state_count = int(g("dist mc states per vertex"))
+    p.volume_phase_p = g("Phase Prob"); p.dist_guide_p = g("dist guide p"); p.volume_forward_project = int(g("volume forward project"))
+    import math
+    d = g("particle size")
+    import numpy as _np
+    p.draine_g = float(_np.float32(math.exp(-2.20679 / (d + 3.91029) - 0.428934))); p.draine_a = float(_np.float32(math.exp(3.62489 - 8.29288 / (d + 5.52825))))
     p.gbuffer_hide_sun = int(g("hide sun")); p.quirk_lc_max_wo_p = int(g("quirk: LC max(wo_p,10)")); p.quirk_n16_wrap = int(g("quirk: 16-bit N*N"))
     if constants is not None:
         for k in range(3):

@@ -169,6 +169,42 @@ def _bsdf_value_f64(wi, wo, rough):
     return ((1 - Fv) / np.pi + F * D * G1(ndotv) * G1(ndoto) / (4 * ndotv * ndoto)) * ndoto
 
 
+def test_draine_phase_and_distance_samplers(o):
+    """Draine phase function integrates to 1, its sampler follows it (mean cosine by quadrature), and
+    the truncated-exponential / Gaussian distance samplers match their pdfs."""
+    g, a = 0.532, 14.6   # particle size 7 um (render_mcpg.cpp:134-135)
+    w, dw = _sphere_quadrature()
+    wi = np.array([0.0, 0.0, 1.0])
+    cos_t = w @ wi
+    g2 = g * g
+    p = (1 / (4 * np.pi)) * (1 - g2) / (1 + g2 - 2 * g * cos_t) ** 1.5 * (1 + a * cos_t ** 2) / (1 + a * (1 + 2 * g2) / 3)
+    assert abs(p.sum() * dw - 1) < 2e-3
+    n = 200000
+    rng = np.random.default_rng(21)
+    x = np.concatenate([np.tile(wi, (n, 1)), np.full((n, 1), g), np.full((n, 1), a), rng.random((n, 2))], 1).astype(np.float32)
+    out = o.math_eval(orc.OP_DRAINE, x).astype(np.float64)
+    assert np.max(np.abs(np.linalg.norm(out[:, :3], axis=1) - 1)) < 1e-5
+    assert abs(out[:, 2].mean() - (p * cos_t).sum() * dw) < 5e-3            # sampler mean cosine == pdf mean cosine
+    ct = out[:, 2]
+    ref = (1 / (4 * np.pi)) * (1 - g2) / (1 + g2 - 2 * g * ct) ** 1.5 * (1 + a * ct ** 2) / (1 + a * (1 + 2 * g2) / 3)
+    assert np.max(np.abs(out[:, 3] / ref - 1)) < 1e-4                        # returned pdf == closed form at the sample
+    hist, edges = np.histogram(ct, bins=20, range=(-1, 1))
+    centers = 0.5 * (edges[1:] + edges[:-1])
+    mass = np.array([p[(cos_t >= lo) & (cos_t < hi)].sum() * dw for lo, hi in zip(edges[:-1], edges[1:])])
+    assert np.max(np.abs(hist / n - mass)) < 4e-3                              # histogram follows the pdf
+    # distance: truncated exponential and Gaussian
+    mu_t, tmax = 2e-3, 800.0
+    y = np.zeros((n, 7), np.float32); y[:, 0] = mu_t; y[:, 1] = tmax; y[:, 2] = rng.random(n); y[:, 3] = 300; y[:, 4] = 40; y[:, 5:7] = rng.random((n, 2))
+    d = o.math_eval(orc.OP_DISTANCE, y).astype(np.float64)
+    assert d[:, 0].min() >= 0 and d[:, 0].max() <= tmax * (1 + 1e-5)
+    xi_max = 1 - np.exp(-mu_t * tmax)
+    expect_mean = (1 / mu_t - (tmax + 1 / mu_t) * np.exp(-mu_t * tmax)) / xi_max
+    assert abs(d[:, 0].mean() / expect_mean - 1) < 0.01
+    assert np.max(np.abs(d[:, 1] / (mu_t * np.exp(-mu_t * d[:, 0]) / xi_max) - 1)) < 1e-4
+    assert abs(d[:, 2].mean() - 300) < 0.5 and abs(d[:, 2].std() - 40) < 0.5
+    assert np.max(np.abs(d[:, 3] / (np.exp(-0.5 * ((d[:, 2] - 300) / 40) ** 2) / (40 * np.sqrt(2 * np.pi))) - 1)) < 1e-3
+
+
 def test_hash_grid_level_width_inverse(o):
     """mc.glsl:65,73: width(level(d)) stays within one level step of the target width."""
     p = orc.json_params()
