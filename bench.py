@@ -88,11 +88,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Rehearsal switch (tests only): all ranks share GPU 0 and the exchange is staged through gloo,
+    # so the N > 1 code path can be exercised on a one-GPU box.  Never set for a measurement.
+    rehearsal = os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     if not torch.cuda.is_available():
@@ -121,7 +129,13 @@ def main():
     def step(frame):
         ctx.process(ctx.synth_camera(frame), True, stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, local)  # the one exchange step: RCCL over xGMI
+            if rehearsal:
+                torch.cuda.synchronize()
+                g_cpu = torch.empty(gathered.numel(), dtype=torch.float32)
+                dist.all_gather_into_tensor(g_cpu, local.cpu())
+                gathered.copy_(g_cpu)
+            else:
+                dist.all_gather_into_tensor(gathered, local)  # the one exchange step: RCCL over xGMI
             ctx.untile(gathered.data_ptr(), stream)
 
     def sync_all():
@@ -144,7 +158,7 @@ def main():
     n_timed, render_sum, update_sum = ctx.timing_get()
     assert n_timed == args.steps
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

@@ -108,6 +108,7 @@ typedef struct mq_counters {
     uint64_t rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels;
     uint64_t queue_rays, queue_nodes, queue_tris; /* the bounce-ray traversal kernel alone */
+    uint64_t queue_overflow;                       /* != 0: a ray queue ran out of room since connect (never expected) */
 } mq_counters;
 
 typedef struct mq_ctx mq_ctx;

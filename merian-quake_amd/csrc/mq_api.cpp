@@ -68,6 +68,7 @@ struct mq_ctx {
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2];
     DevBuf d_prev_vdepth, d_dist_mc;
     uint32_t dist_mc_n = 0;
+    uint32_t ray_cap = 0;
     uint32_t queue_cap = 0;
     uint32_t mc_total = 0, lc_total = 0;
     uint64_t iteration = 0;
@@ -364,7 +365,7 @@ int mq_set_property(mq_ctx* c, const char* key, double value) {
     const PropDesc* d = find_prop(key);
     if (!d) return fail(c, MQ_EUNKNOWN_KEY, std::string("unknown property: ") + key);
     if (!strcmp(key, "mc samples") && (value < 0 || value > MQ_MAX_MC_SAMPLES)) return fail(c, MQ_EINVAL, "mc samples must be in [0, 8] in this build");
-    if (d->type == PT_OPTION && !(!strcmp(key, "debug output") && value >= 100)) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
+    if (d->type == PT_OPTION) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
     bool changed = prop_set(c->props, *d, value);
     if (changed) c->params_dirty = true;
     if (changed && d->reconnect) { c->connected = false; return 1; } // NEEDS_RECONNECT, render_mcpg.cpp:567-575
@@ -607,10 +608,11 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_spill, (size_t)c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
     const size_t slots = (size_t)c->tiles_per_rank * 64;
     if ((r = dev_alloc(c, c->d_paths, slots * 160))) return r;
-    if ((r = dev_alloc(c, c->d_rays, slots * 32))) return r;
-    if ((r = dev_alloc(c, c->d_ray_hits, slots * 16))) return r;
-    if ((r = dev_alloc(c, c->d_qslots[0], slots * 4))) return r;
-    if ((r = dev_alloc(c, c->d_qslots[1], slots * 4))) return r;
+    c->ray_cap = (uint32_t)(2 * slots + 1024); // sharded queues interleave 16 tails: room for shard imbalance
+    if ((r = dev_alloc(c, c->d_rays, (size_t)c->ray_cap * 32))) return r;
+    if ((r = dev_alloc(c, c->d_ray_hits, (size_t)c->ray_cap * 16))) return r;
+    if ((r = dev_alloc(c, c->d_qslots[0], (size_t)c->ray_cap * 4))) return r;
+    if ((r = dev_alloc(c, c->d_qslots[1], (size_t)c->ray_cap * 4))) return r;
     if ((r = dev_alloc(c, c->d_prev_vdepth, (size_t)w * h * 2))) return r;
     HIPCHK(c, hipMemset(c->d_prev_vdepth.p, 0, c->d_prev_vdepth.bytes));
     c->dist_mc_n = (uint32_t)(d.state_bytes_volume_distancemc / sizeof(MqDistMC));
@@ -647,10 +649,10 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.gb_albedo = (uint16_t*)c->d_out[MQ_OUT_GB_ALBEDO].p; F.gb_irr = (uint16_t*)c->d_out[MQ_OUT_GB_IRRADIANCE].p;
     F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
-    F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.counters = (MqCountersDev*)c->d_counters.p;
+    F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.counters = (MqCountersDev*)c->d_counters.p; F.count_stats = c->count_enabled ? 1u : 0u;
     F.stack_spill = (unsigned long long*)c->d_spill.p;
     F.paths = (uint4*)c->d_paths.p; F.rays = (float4*)c->d_rays.p; F.ray_hits = (uint4*)c->d_ray_hits.p;
-    F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p;
+    F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p; F.ray_cap = c->ray_cap;
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
     F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
 }
@@ -708,7 +710,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     }
     // ---- volume passes, render_mcpg.cpp:280-320 (their device time is part of the update interval) ----
-    if (guided) HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_UPDATES, 0, 4, s)); // queue consumed; volume entries start at 0
+    if (guided) HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_UPDATES, 0, 4 * MQ_CTRL_GROUP, s)); // queue consumed; volume entries start at 0
     if (volume) {
         const size_t px = (size_t)c->W * c->H;
         HIPCHK(c, hipMemcpyAsync(c->d_prev_vdepth.p, c->d_out[MQ_OUT_VOLUME_DEPTH].p, px * 2, hipMemcpyDeviceToDevice, s)); // delay-1 feedback connector
@@ -800,6 +802,9 @@ int mq_get_counters(mq_ctx* c, mq_counters* out) {
     out->lc_touches = d.lc_touches; out->mc_updates_accepted = d.mc_updates_accepted; out->mc_updates_dropped = d.mc_updates_dropped;
     out->mc_state_reads = d.mc_state_reads; out->pixels = d.pixels;
     out->queue_rays = d.q_rays; out->queue_nodes = d.q_nodes; out->queue_tris = d.q_tris;
+    uint32_t flag = 0;
+    HIPCHK(c, hipMemcpy(&flag, c->d_ctrl.p, 4, hipMemcpyDeviceToHost));
+    out->queue_overflow = flag;
     return MQ_OK;
 }
 

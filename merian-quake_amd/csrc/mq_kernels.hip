@@ -40,6 +40,9 @@ struct Hit { // res/shader/hit.glsl.h:6-17
     float roughness;
 };
 
+// position of entry k of shard `shard` in a sharded queue (see "sharded queues" below)
+MQ_DEV uint32_t shard_pos(uint32_t shard, uint32_t k) { return (((k >> 6) * MQ_SHARDS + shard) << 6) | (k & 63u); }
+
 struct Ctr { uint32_t rays, nodes, tris, segments, guided, lc, upd_ok, upd_drop, mc_reads, pixels, lc_ok, lc_cancel; };
 
 // ------------------------------------------------------------------------------------------------
@@ -47,27 +50,40 @@ struct Ctr { uint32_t rays, nodes, tris, segments, guided, lc, upd_ok, upd_drop,
 // ------------------------------------------------------------------------------------------------
 struct f4 { float r, g, b, a; };
 
-MQ_DEV int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
-
-MQ_DEV f4 texel(const MqSceneDev& sc, const MqTexDesc& t, int x, int y) {
-    uint32_t p = sc.texels[t.offset + (uint32_t)wrapi(y, (int)t.h) * t.w + (uint32_t)wrapi(x, (int)t.w)];
+// REPEAT addressing without integer division: u = s - floor(s) in [0,1], then scale by the size
+MQ_DEV f4 texel(const MqSceneDev& sc, const MqTexDesc& t, int x, int y) { // x, y already in range
+    uint32_t p = sc.texels[t.offset + (uint32_t)y * t.w + (uint32_t)x];
     f4 r;
     if (t.flags & MQ_TEX_SRGB) { r.r = sc.srgb_lut[p & 0xff]; r.g = sc.srgb_lut[(p >> 8) & 0xff]; r.b = sc.srgb_lut[(p >> 16) & 0xff]; }
     else { r.r = (float)(p & 0xff) * (1.0f / 255.0f); r.g = (float)((p >> 8) & 0xff) * (1.0f / 255.0f); r.b = (float)((p >> 16) & 0xff) * (1.0f / 255.0f); }
     r.a = (float)(p >> 24) * (1.0f / 255.0f);
     return r;
 }
+MQ_DEV int tex_nearest_coord(float s, float fw, int w) {
+    float u = s - floorf(s);
+    int i = (int)floorf(u * fw);
+    return i > w - 1 ? w - 1 : i;
+}
+MQ_DEV void tex_linear_coord(float s, float fw, int w, int& i0, int& i1, float& f) {
+    float u = s - floorf(s);
+    float x = u * fw - 0.5f;
+    float x0 = floorf(x);
+    f = x - x0;
+    int a = (int)x0, b = a + 1;
+    if (a < 0) a += w;
+    if (b >= w) b -= w;
+    i0 = a; i1 = b;
+}
 MQ_DEV f4 tex_sample(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
     if (texnum > MQ_MAX_GLTEXTURES - 1) texnum = MQ_MAX_GLTEXTURES - 1;
     MqTexDesc tx = sc.tex[texnum];
     if (tx.offset == MQ_NIL) { f4 g; g.r = g.g = g.b = 0.5f; g.a = 1.0f; return g; }
     float fw = (float)tx.w, fh = (float)tx.h;
-    if (!(tx.flags & MQ_TEX_LINEAR)) return texel(sc, tx, (int)floorf(s * fw), (int)floorf(t * fh));
-    float x = s * fw - 0.5f, y = t * fh - 0.5f;
-    float x0 = floorf(x), y0 = floorf(y);
-    float fx = x - x0, fy = y - y0;
-    int ix = (int)x0, iy = (int)y0;
-    f4 a = texel(sc, tx, ix, iy), b = texel(sc, tx, ix + 1, iy), d = texel(sc, tx, ix, iy + 1), e = texel(sc, tx, ix + 1, iy + 1);
+    if (!(tx.flags & MQ_TEX_LINEAR)) return texel(sc, tx, tex_nearest_coord(s, fw, (int)tx.w), tex_nearest_coord(t, fh, (int)tx.h));
+    int x0, x1, y0, y1; float fx, fy;
+    tex_linear_coord(s, fw, (int)tx.w, x0, x1, fx);
+    tex_linear_coord(t, fh, (int)tx.h, y0, y1, fy);
+    f4 a = texel(sc, tx, x0, y0), b = texel(sc, tx, x1, y0), d = texel(sc, tx, x0, y1), e = texel(sc, tx, x1, y1);
     f4 r;
     r.r = mmix(mmix(a.r, b.r, fx), mmix(d.r, e.r, fx), fy);
     r.g = mmix(mmix(a.g, b.g, fx), mmix(d.g, e.g, fx), fy);
@@ -79,8 +95,10 @@ MQ_DEV float tex_gather_alpha_r(const MqSceneDev& sc, uint32_t texnum, float s, 
     if (texnum > MQ_MAX_GLTEXTURES - 1) texnum = MQ_MAX_GLTEXTURES - 1;
     MqTexDesc tx = sc.tex[texnum];
     if (tx.offset == MQ_NIL) return 1.0f;
-    int ix = (int)floorf(s * (float)tx.w - 0.5f), iy = (int)floorf(t * (float)tx.h - 0.5f);
-    return texel(sc, tx, ix, iy + 1).a;
+    int x0, x1, y0, y1; float fx, fy;
+    tex_linear_coord(s, (float)tx.w, (int)tx.w, x0, x1, fx);
+    tex_linear_coord(t, (float)tx.h, (int)tx.h, y0, y1, fy);
+    return texel(sc, tx, x0, y1).a;
 }
 
 MQ_DEV mq_ext load_ext(const MqSceneDev& sc, uint32_t key) {
@@ -575,7 +593,17 @@ MQ_DEV void enqueue_update(const MqParams& P, const MqFrame& F, uint32_t& rng, u
     uint32_t cnt = __hip_atomic_load(&F.upd_count[index], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cnt < MQ_MAX_UPDATES) {
         __hip_atomic_fetch_add(&F.upd_count[index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t uq = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES], 1u);
+        uint32_t uq = 0;
+        { // wave-aggregated append to this wave's shard of the update queue (lanes arrive here divergently)
+            unsigned long long m = __ballot(1);
+            const int lane = threadIdx.x & 63;
+            const uint32_t shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MQ_SHARDS - 1);
+            int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES + shard * MQ_SHARD_STRIDE], (uint32_t)__popcll(m));
+            base = __shfl(base, leader, 64);
+            uq = shard_pos(shard, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+        }
         if (uq < F.queue_cap) {
             uint4* e = (uint4*)(F.queue + uq);
             e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(w));
@@ -748,19 +776,45 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
     return false;
 }
 
-// Appends the lanes with `push` set to the queue of round `round`: one atomic per wave.
-MQ_DEV uint32_t queue_append(const MqFrame& F, int round, bool push) {
+// ---- sharded queues ------------------------------------------------------------------------------
+// A queue has MQ_SHARDS tails; shard s owns every 16th BLOCK of 64 positions: entry k of shard s sits
+// at ((k / 64) * 16 + s) * 64 + k % 64, so the (up to 64) entries one wave appends stay adjacent and
+// a consumer wave reading 64 consecutive positions sees the rays of neighbouring pixels.  A wave
+// appends to the shard of its wave id with ONE atomic (ballot + prefix popcount).  Consumers walk
+// positions [0, n_eff) and skip the holes behind shorter shards.
+struct QView { uint32_t cnt; uint32_t n_eff; }; // cnt: tail of shard (lane & 15) in every lane; n_eff = 1024 * ceil(max tail / 64)
+MQ_DEV QView queue_view(const uint32_t* tails) {
+    const int lane = threadIdx.x & 63;
+    QView v;
+    v.cnt = tails[(lane & (MQ_SHARDS - 1)) * MQ_SHARD_STRIDE];
+    uint32_t m = v.cnt;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+    v.n_eff = ((m + 63u) >> 6) * (64u * MQ_SHARDS);
+    return v;
+}
+MQ_DEV bool queue_valid(const QView& v, uint32_t q) {
+    const uint32_t shard = (q >> 6) & (MQ_SHARDS - 1), k = ((q >> 10) << 6) | (q & 63u);
+    return k < (uint32_t)__shfl((int)v.cnt, (int)shard, 64);
+}
+MQ_DEV uint32_t shard_append(uint32_t* tails, bool push) { // returns the interleaved position (valid where push)
     unsigned long long m = __ballot(push);
-    uint32_t my = 0;
+    uint32_t pos = 0;
     if (m) {
         const int lane = threadIdx.x & 63;
+        const uint32_t shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MQ_SHARDS - 1);
         int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&F.ctrl[MQ_CTRL_QUEUE0 + round], (uint32_t)__popcll(m));
+        if (lane == leader) base = atomicAdd(&tails[shard * MQ_SHARD_STRIDE], (uint32_t)__popcll(m));
         base = __shfl(base, leader, 64);
-        my = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        pos = shard_pos(shard, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
     }
-    return my;
+    return pos;
+}
+MQ_DEV uint32_t queue_append(const MqFrame& F, int round, bool& push) {
+    uint32_t q = shard_append(F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP, push);
+    if (push && q >= F.ray_cap) { atomicOr(&F.ctrl[0], 1u); push = false; } // cannot happen with the 2x margin; flagged, never silent
+    return q;
 }
 MQ_DEV void emit_ray(const MqFrame& F, int round, uint32_t q, uint32_t slot, const Path& p) {
     f3 ro = p.cur.pos - p.cur.wi * 1e-3f; // mcpg.comp:144
@@ -847,14 +901,15 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
         uint32_t q = queue_append(F, 0, cont);
         if (cont) emit_ray(F, 0, q, my, p);
     }
-    if (COUNT || GUIDED) flush_counters(F.counters, ctr);
+    if (COUNT) flush_counters(F.counters, ctr);
 }
 
 // ---- closest hit for every queued ray ------------------------------------------------------------
 // Persistent waves with dynamic ray fetch: a lane whose ray is finished takes the next ray of its
 // wave's pool instead of idling until the longest traversal of the wave ends; pools are refilled
-// MQ_TRACE_CHUNK rays at a time with one atomic per wave, so the shared head word sees ~n/256 atomics.
-#define MQ_TRACE_CHUNK 256u
+// MQ_TRACE_BLOCKS blocks of its home shard at a time (one atomic on one of 16 per-shard heads), moving on
+// to the other shards when the home shard is drained, so no single word sees more than ~n/2048 atomics.
+#define MQ_TRACE_BLOCKS 4u // most 64-entry blocks fetched per refill (fewer for small queues, so that every resident wave gets rays)
 #ifndef MQ_TRI_VOTE
 #define MQ_TRI_VOTE 16u
 #endif
@@ -865,13 +920,21 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     uint2* stk = &s_stack[threadIdx.x >> 6][0][lane];
     const uint32_t gid = blockIdx.x * MQ_BLOCK + threadIdx.x;
     unsigned long long* spill = F.stack_spill + (size_t)gid * MQ_SPILL_ENTRIES;
-    const uint32_t n = F.ctrl[MQ_CTRL_QUEUE0 + round];
+    const uint32_t* tails = F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP;
+    uint32_t* heads = F.ctrl + MQ_CTRL_HEAD0 + round * MQ_CTRL_GROUP;
     Ctr ctr = {};
-    uint32_t pool_next = 0, pool_end = 0; // wave-uniform
-    bool exhausted = n == 0 || sc.n_nodes == 0;
+    const uint32_t wave_id = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
     if (sc.n_nodes == 0) { // empty scene: every ray misses
-        for (uint32_t q = gid; q < n; q += gridDim.x * MQ_BLOCK) F.ray_hits[q] = make_uint4(MQ_NIL, 0x7f800000u, 0u, 0u);
+        const QView qv = queue_view(tails);
+        for (uint32_t q = gid; q < qv.n_eff; q += gridDim.x * MQ_BLOCK) F.ray_hits[q] = make_uint4(MQ_NIL, 0x7f800000u, 0u, 0u);
+        return;
     }
+    // The wave's pool: `pool_len` entries of shard `pool_s`, starting at entry 64 * pool_j of that shard
+    // (a run of MQ_TRACE_BLOCKS 64-entry blocks); `pool_i` entries are already handed out.  All wave-uniform.
+    uint32_t pool_s = wave_id & (MQ_SHARDS - 1), pool_j = 0, pool_i = 0, pool_len = 0;
+    const uint32_t per_wave = queue_view(tails).n_eff / (gridDim.x * MQ_WAVES);
+    const uint32_t nblk = per_wave >= 64u * MQ_TRACE_BLOCKS ? MQ_TRACE_BLOCKS : (per_wave >= 128u ? 2u : 1u);
+    bool exhausted = false;
     bool busy = false;
     uint32_t q = 0;
     Trav t;
@@ -879,24 +942,46 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     for (;;) {
         unsigned long long idle = __ballot(!busy);
         if (idle) {
-            if (pool_next == pool_end && !exhausted) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&F.ctrl[MQ_CTRL_HEAD0 + round], MQ_TRACE_CHUNK);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base >= n) { exhausted = true; pool_next = pool_end = 0; }
-                else { pool_next = base; pool_end = base + MQ_TRACE_CHUNK < n ? base + MQ_TRACE_CHUNK : n; }
+            while (pool_i == pool_len && !exhausted) { // refill: next run of blocks of the current shard
+                uint32_t cnt = 0, head = 0;
+                if (lane == 0) { cnt = tails[pool_s * MQ_SHARD_STRIDE]; head = __hip_atomic_load(&heads[pool_s * MQ_SHARD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt); head = (uint32_t)__builtin_amdgcn_readfirstlane((int)head);
+                bool got = false;
+                if (head * 64u < cnt) { // look before bumping: a failed atomic on a shared line is the expensive case
+                    uint32_t j = 0;
+                    if (lane == 0) j = atomicAdd(&heads[pool_s * MQ_SHARD_STRIDE], nblk);
+                    j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+                    if (j * 64u < cnt) {
+                        pool_j = j; pool_i = 0;
+                        const uint32_t rest = cnt - j * 64u;
+                        pool_len = rest < 64u * nblk ? rest : 64u * nblk;
+                        got = true;
+                    }
+                }
+                if (!got) { // this shard is drained: probe all 16 shards in one round trip (lanes 0..15) and move to the next one with rays
+                    const uint32_t sh = (uint32_t)lane & (MQ_SHARDS - 1);
+                    const uint32_t c16 = tails[sh * MQ_SHARD_STRIDE];
+                    const uint32_t h16 = __hip_atomic_load(&heads[sh * MQ_SHARD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t has = (uint32_t)(__ballot(h16 * 64u < c16) & 0xffffull);
+                    if (!has) exhausted = true;
+                    else {
+                        const uint32_t rot = ((has >> pool_s) | (has << (MQ_SHARDS - pool_s))) & 0xffffu; // bit i = shard (pool_s + i) & 15
+                        pool_s = (pool_s + (uint32_t)__ffs((int)rot) - 1u) & (MQ_SHARDS - 1);
+                    }
+                }
             }
-            const uint32_t avail = pool_end - pool_next;
+            const uint32_t avail = pool_len - pool_i;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!busy && rank < avail) {
-                q = pool_next + rank;
+                const uint32_t i = pool_i + rank;
+                q = shard_pos(pool_s, (pool_j << 6) + i);
                 float4 o = F.rays[2 * (size_t)q], d = F.rays[2 * (size_t)q + 1];
                 trav_init(t, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), MQ_T_MAX);
                 busy = true;
                 if (COUNT) ctr.rays++;
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
-            pool_next += n_idle < avail ? n_idle : avail;
+            pool_i += n_idle < avail ? n_idle : avail;
         }
         if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
         // node phase: lanes without pending triangles visit one node
@@ -935,7 +1020,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
     __shared__ float s_lobes[GUIDED ? MQ_WAVES : 1][GUIDED ? 6 * MQ_MAX_MC_SAMPLES : 1][64];
     float* lobes = GUIDED ? &s_lobes[threadIdx.x >> 6][0][threadIdx.x & 63] : nullptr;
     const mq_uniform& U = F.u;
-    const uint32_t n = F.ctrl[MQ_CTRL_QUEUE0 + round];
+    const QView qv = queue_view(F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const uint32_t n = qv.n_eff;
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
     const uint32_t stride = gridDim.x * MQ_BLOCK;
@@ -945,17 +1031,15 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
         bool cont = false;
         uint32_t slot = 0;
         Path p = {};
-        if (q < n) {
+        const bool valid = queue_valid(qv, q < n ? q : 0u);
+        if (q < n && valid) {
             slot = F.queue_slots[round & 1][q];
             load_path(F.paths + 10 * (size_t)slot, p);
             uint4 hq = F.ray_hits[q];
-            const int abl = P.debug_output_selector; // >= 101: timing ablation stages (diagnostic only)
-            if (abl == 101) { F.tiles_out[4 * (size_t)slot] = p.thr.x + __uint_as_float(hq.y); continue; }
             RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
             Hit next; next.wi = p.wo; next.pos = p.cur.pos - p.cur.wi * 1e-3f; next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
             f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
             shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
-            if (abl == 102) { F.tiles_out[4 * (size_t)slot] = incident.x + next.albedo.x + next.pos.x + throughput.x; continue; }
             f3 lc_incident; // mcpg.comp:149
             if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
             else { lc_incident = rh3(throughput * light_cache_get(P, U, F.lc, p.rng, next.pos, next.normal)); if (COUNT) ctr.lc++; }
@@ -964,28 +1048,22 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             else p.fval = p.thr * incident;
             p.pp *= p.wo_p;
             p.thr = p.thr * throughput;
-            if (abl == 103) { F.tiles_out[4 * (size_t)slot] = p.thr.x + p.fval.x + lc_incident.x + next.pos.x; continue; }
             if (GUIDED) { // mcpg.comp:165-181
                 float mc_f = luminance((lc_incident * p.bsdf) * (1.0f / p.wo_p));
                 if (mfinite(mc_f)) {
                     float den = P.quirk_lc_max_wo_p ? mmax(p.wo_p, 10.0f) : mmax(p.wo_p, 1e-6f);
-#ifndef MQ_ABL_NOLC
-                    if (abl != 105 && abl != 107)
                     light_cache_update(P, U, F.lc, p.rng, p.cur.pos, p.cur.normal, ((lc_incident * (p.cur.albedo * MQ_INV_PI)) * p.wodotn) * (1.0f / den), ctr);
-#endif
                     if (COUNT) ctr.lc++;
-                    if (abl == 106 || abl == 107) {
-                    } else if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
+                    if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
                         f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
                         enqueue_update(P, F, p.rng, p.mc_index, p.mc_id, p.cur.pos, mc_f, next.pos, mv, p.cur.normal, ctr);
-                    } else if (abl != 108 && P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
+                    } else if (P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
                         F.mc[p.mc_index].sum_w = 0.0f; // mcpg.comp:177
                     }
                 }
             }
             p.thr = p.thr * next.albedo; // :184
             p.cur = next;
-            if (abl == 104) { F.tiles_out[4 * (size_t)slot] = p.thr.x + p.fval.x + next.pos.x + __uint_as_float(p.rng); continue; }
             bool need_dir = false, sample_done = false;
             if ((p.thr.x < 1e-7f && p.thr.y < 1e-7f && p.thr.z < 1e-7f) || (p.fval.x > 1e-7f || p.fval.y > 1e-7f || p.fval.z > 1e-7f)) sample_done = true;
             else { p.seg++; if (p.seg < P.max_path_length) need_dir = true; else sample_done = true; }
@@ -994,7 +1072,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
         uint32_t qn = queue_append(F, round + 1, cont);
         if (cont) emit_ray(F, round + 1, qn, slot, p);
     }
-    if (COUNT || GUIDED) flush_counters(F.counters, ctr);
+    if (COUNT) flush_counters(F.counters, ctr);
 }
 
 
@@ -1217,13 +1295,18 @@ template <bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel(MqSceneDev sc, MqParams P, MqFrame F, int smp, int round) {
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
-    const uint32_t n = F.ctrl[MQ_CTRL_QUEUE0 + round];
+    const QView qv = queue_view(F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const uint32_t n = qv.n_eff;
     const uint32_t grid_max_x = F.W / (uint32_t)P.distance_mc_grid_width + 1u;
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     const f3 mu_s = F3(U.prev_cam_x[3], U.prev_cam_w[3], U.prev_cam_u[3]);
     const float mu_t = U.cam_x[3];
     Ctr ctr = {};
-    for (uint32_t q = blockIdx.x * MQ_BLOCK + threadIdx.x; q < n; q += gridDim.x * MQ_BLOCK) {
+    const uint32_t vstride = gridDim.x * MQ_BLOCK;
+    for (uint32_t it = 0; it < (n + vstride - 1) / vstride; it++) {
+        const uint32_t q = it * vstride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        const bool valid = queue_valid(qv, q < n ? q : 0u);
+        if (!(q < n && valid)) continue;
         const uint32_t slot = F.queue_slots[round & 1][q];
         VPath v;
         load_vpath(F.paths + 10 * (size_t)slot, v);
@@ -1295,8 +1378,13 @@ MQ_DEV void mc_update(MCS& s, f3 pos, float w, f3 target, const uint16_t* mv) { 
 
 // pass A: chain the queue entries of each slot (newest first) through `next`
 __global__ __launch_bounds__(256) void mq_link_kernel(MqFrame F) {
-    uint32_t n = F.ctrl[MQ_CTRL_UPDATES] < F.queue_cap ? F.ctrl[MQ_CTRL_UPDATES] : F.queue_cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const QView qv = queue_view(F.ctrl + MQ_CTRL_UPDATES);
+    const uint32_t n = qv.n_eff < F.queue_cap ? qv.n_eff : F.queue_cap;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
+        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = queue_valid(qv, i < n ? i : 0u);
+        if (!(i < n && valid)) continue;
         uint32_t* e3 = (uint32_t*)(F.queue + i) + 12;
         uint32_t prev = atomicExch(&F.upd_head[e3[2]], i + 1u);
         e3[3] = prev;
@@ -1307,9 +1395,14 @@ __global__ __launch_bounds__(256) void mq_link_kernel(MqFrame F) {
 // first MQ_MAX_UPDATES arrivals (the reference drops later arrivals at enqueue time, mc.glsl:169-184)
 __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
     const mq_uniform& U = F.u;
-    uint32_t n = F.ctrl[MQ_CTRL_UPDATES] < F.queue_cap ? F.ctrl[MQ_CTRL_UPDATES] : F.queue_cap;
+    const QView qv = queue_view(F.ctrl + MQ_CTRL_UPDATES);
+    const uint32_t n = qv.n_eff < F.queue_cap ? qv.n_eff : F.queue_cap;
     uint32_t accepted = 0, dropped = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
+        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = queue_valid(qv, i < n ? i : 0u);
+        if (!(i < n && valid)) continue;
         const uint4* e = (const uint4*)(F.queue + i);
         uint4 e3 = e[3];
         uint32_t slot = e3.z;
@@ -1356,7 +1449,7 @@ __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
     }
     // statistics: accepted / dropped-by-cap updates of this frame
     for (int off = 32; off > 0; off >>= 1) { accepted += __shfl_down(accepted, off, 64); dropped += __shfl_down(dropped, off, 64); }
-    if ((threadIdx.x & 63) == 0) {
+    if (F.count_stats && (threadIdx.x & 63) == 0) {
         if (accepted) atomicAdd(&F.counters->mc_updates_accepted, (unsigned long long)accepted);
         if (dropped) atomicAdd(&F.counters->mc_updates_dropped, (unsigned long long)dropped);
     }

@@ -22,11 +22,17 @@
 #define MQ_BARY_EPS 3.814697265625e-06f
 #define MQ_NIL 0xffffffffu
 #define MQ_WIDTH_LUT 48
-#define MQ_CTRL_UPDATES 1
-#define MQ_CTRL_QUEUE0 2
+// Control words.  Every counter that many waves bump is SHARDED 16 ways, one 128-byte line per shard
+// (atomics on one line serialise at about 88/us on this chip, whichever word of the line they hit):
+// shard s of a queue owns every 16th block of 64 positions.
+#define MQ_SHARDS 16
+#define MQ_SHARD_STRIDE 32                                  // words between the counters of two shards (128 B)
 #define MQ_MAX_ROUNDS 30
-#define MQ_CTRL_HEAD0 (MQ_CTRL_QUEUE0 + MQ_MAX_ROUNDS + 1)
-#define MQ_CTRL_WORDS 64
+#define MQ_CTRL_GROUP (MQ_SHARDS * MQ_SHARD_STRIDE)         // words of one sharded counter
+#define MQ_CTRL_UPDATES MQ_CTRL_GROUP                       // update-queue tails (group 1; group 0 holds the overflow flag)
+#define MQ_CTRL_QUEUE0 (2 * MQ_CTRL_GROUP)                  // ray-queue tails, one group per round
+#define MQ_CTRL_HEAD0 (MQ_CTRL_QUEUE0 + (MQ_MAX_ROUNDS + 1) * MQ_CTRL_GROUP) // traversal fetch heads (64-entry blocks), one group per round
+#define MQ_CTRL_WORDS (MQ_CTRL_HEAD0 + (MQ_MAX_ROUNDS + 1) * MQ_CTRL_GROUP)
 
 // 80-byte compressed 8-wide BVH node (Ylitie et al. 2017 layout).
 struct MqNode {
@@ -180,8 +186,7 @@ struct MqFrame {
     uint32_t* upd_head;    // per mc slot, index+1 of the newest queue entry
     MqUpdate* queue;
     uint32_t queue_cap;
-    // control words: [MQ_CTRL_UPDATES] update-queue tail, [MQ_CTRL_QUEUE0 + r] ray count of round r,
-    // [MQ_CTRL_HEAD0 + r] fetch head of round r's traversal kernel
+    // control words: see MQ_CTRL_* (sharded tails of the update queue and of every round's ray queue, fetch heads)
     uint32_t* ctrl;
     // wavefront state: 160-byte path records per pixel slot, rays / hits per queue position,
     // ping-pong queues of pixel slots
@@ -189,7 +194,9 @@ struct MqFrame {
     float4* rays;
     uint4* ray_hits;
     uint32_t* queue_slots[2];
+    uint32_t ray_cap;      // positions available in rays / ray_hits / queue_slots (2x the pixel slots: shard imbalance margin)
     MqCountersDev* counters;
+    uint32_t count_stats;  // != 0: kernels without a COUNT instantiation may bump `counters` too
     // traversal stack spill area: MQ_SPILL_ENTRIES 8-byte entries per resident lane
     unsigned long long* stack_spill;
 };

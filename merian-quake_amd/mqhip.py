@@ -54,7 +54,7 @@ class IoDesc(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "tris", "segments", "guided_segments", "lc_touches",
-                                          "mc_updates_accepted", "mc_updates_dropped", "mc_state_reads", "pixels", "queue_rays", "queue_nodes", "queue_tris")]
+                                          "mc_updates_accepted", "mc_updates_dropped", "mc_state_reads", "pixels", "queue_rays", "queue_nodes", "queue_tris", "queue_overflow")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

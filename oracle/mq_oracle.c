@@ -194,14 +194,30 @@ int orc_set_texture(orc_ctx* c, uint32_t texnum, uint32_t w, uint32_t h, const u
 
 typedef struct { float r, g, b, a; } v4;
 
-static inline int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
-static inline v4 texel(const orc_ctx* c, const tex_t* t, int x, int y) {
-    const uint8_t* p = t->px + 4 * ((size_t)wrapi(y, (int)t->h) * t->w + (size_t)wrapi(x, (int)t->w));
+/* REPEAT addressing without integer division: u = s - floor(s) in [0,1], then scale by the size */
+static inline v4 texel(const orc_ctx* c, const tex_t* t, int x, int y) { /* x, y already in range */
+    const uint8_t* p = t->px + 4 * ((size_t)y * t->w + (size_t)x);
     v4 r;
     if (t->flags & ORC_TEX_SRGB) { r.r = c->srgb_lut[p[0]]; r.g = c->srgb_lut[p[1]]; r.b = c->srgb_lut[p[2]]; }
     else { r.r = (float)p[0] * (1.0f / 255.0f); r.g = (float)p[1] * (1.0f / 255.0f); r.b = (float)p[2] * (1.0f / 255.0f); }
     r.a = (float)p[3] * (1.0f / 255.0f);
     return r;
+}
+static inline int tex_nearest_coord(float s, float fw, int w) {
+    float u = s - floorf(s);
+    int i = (int)floorf(u * fw);
+    return i > w - 1 ? w - 1 : i;
+}
+/* bilinear footprint along one axis: texel indices i0, i1 (wrapped) and the weight of i1 */
+static inline void tex_linear_coord(float s, float fw, int w, int* i0, int* i1, float* f) {
+    float u = s - floorf(s);
+    float x = u * fw - 0.5f;
+    float x0 = floorf(x);
+    *f = x - x0;
+    int a = (int)x0, b = a + 1;
+    if (a < 0) a += w;
+    if (b >= w) b -= w;
+    *i0 = a; *i1 = b;
 }
 /* textureLod(img_tex[texnum], st, 0) with REPEAT wrap; nearest or bilinear per texture.
  * A texture slot that was never uploaded samples as opaque mid grey. */
@@ -210,14 +226,11 @@ static v4 tex_sample(const orc_ctx* c, uint32_t texnum, float s, float t) {
     const tex_t* tx = &c->tex[texnum];
     if (!tx->px) { v4 g = {0.5f, 0.5f, 0.5f, 1.0f}; return g; }
     float fw = (float)tx->w, fh = (float)tx->h;
-    if (!(tx->flags & ORC_TEX_LINEAR)) {
-        return texel(c, tx, (int)floorf(s * fw), (int)floorf(t * fh));
-    }
-    float x = s * fw - 0.5f, y = t * fh - 0.5f;
-    float x0 = floorf(x), y0 = floorf(y);
-    float fx = x - x0, fy = y - y0;
-    int ix = (int)x0, iy = (int)y0;
-    v4 a = texel(c, tx, ix, iy), b = texel(c, tx, ix + 1, iy), d = texel(c, tx, ix, iy + 1), e = texel(c, tx, ix + 1, iy + 1);
+    if (!(tx->flags & ORC_TEX_LINEAR)) return texel(c, tx, tex_nearest_coord(s, fw, (int)tx->w), tex_nearest_coord(t, fh, (int)tx->h));
+    int x0, x1, y0, y1; float fx, fy;
+    tex_linear_coord(s, fw, (int)tx->w, &x0, &x1, &fx);
+    tex_linear_coord(t, fh, (int)tx->h, &y0, &y1, &fy);
+    v4 a = texel(c, tx, x0, y0), b = texel(c, tx, x1, y0), d = texel(c, tx, x0, y1), e = texel(c, tx, x1, y1);
     v4 r;
     r.r = omix(omix(a.r, b.r, fx), omix(d.r, e.r, fx), fy);
     r.g = omix(omix(a.g, b.g, fx), omix(d.g, e.g, fx), fy);
@@ -225,13 +238,15 @@ static v4 tex_sample(const orc_ctx* c, uint32_t texnum, float s, float t) {
     r.a = omix(omix(a.a, b.a, fx), omix(d.a, e.a, fx), fy);
     return r;
 }
-/* textureGather(tex, st, 3).r : alpha of footprint texel (i0, j0+1) */
+/* textureGather(tex, st, 3).r : alpha of footprint texel (i0, j1) */
 static float tex_gather_alpha_r(const orc_ctx* c, uint32_t texnum, float s, float t) {
     if (texnum > MAX_GLTEXTURES - 1) texnum = MAX_GLTEXTURES - 1;
     const tex_t* tx = &c->tex[texnum];
     if (!tx->px) return 1.0f;
-    int ix = (int)floorf(s * (float)tx->w - 0.5f), iy = (int)floorf(t * (float)tx->h - 0.5f);
-    return texel(c, tx, ix, iy + 1).a;
+    int x0, x1, y0, y1; float fx, fy;
+    tex_linear_coord(s, (float)tx->w, (int)tx->w, &x0, &x1, &fx);
+    tex_linear_coord(t, (float)tx->h, (int)tx->h, &y0, &y1, &fy);
+    return texel(c, tx, x0, y1).a;
 }
 
 /* ---------------------------------------------------------------- intersection */
