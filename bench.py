@@ -157,6 +157,8 @@ def main():
     # recorded on the launch stream inside mq_process)
     n_timed, render_sum, update_sum = ctx.timing_get()
     assert n_timed == args.steps
+    det = ctx.timing_detail()
+    per_round = ctx.timing_rounds()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -171,16 +173,16 @@ def main():
     c = ctx.counters()
     ctx.enable_counters(False)
     local_pixels = c["pixels"]
-    det = ctx.timing_detail()
     kms = {"mq_primary_kernel": det["primary_ms"] / n_timed, "mq_trace_queue_kernel": det["trace_ms"] / n_timed,
            "mq_bounce_kernel": det["bounce_ms"] / n_timed, "mq_apply_kernel": update_sum / n_timed}
     rounds = args.spp * 2  # spp * (max path length - 1) launches of trace + bounce per frame
     # algorithmic bytes per kernel class (SURVEY.md 8d prices)
     prim_rays = c["rays"] - c["queue_rays"]
+    bounce_rays = c["queue_rays"]
     kbytes = {
         "mq_primary_kernel": local_pixels * 56 + 80 * (c["nodes"] - c["queue_nodes"]) + 48 * (c["tris"] - c["queue_tris"]) + 120 * prim_rays,
         "mq_trace_queue_kernel": 80 * c["queue_nodes"] + 48 * c["queue_tris"] + 48 * c["queue_rays"],   # + 32 B ray in, 16 B hit out
-        "mq_bounce_kernel": c["queue_rays"] * (120 + 16 + 4 + 320) + 64 * c["mc_state_reads"] + 24 * c["lc_touches"] + 64 * c["mc_updates_accepted"],
+        "mq_bounce_kernel": bounce_rays * (120 + 16 + 4 + 320) + 64 * c["mc_state_reads"] + 24 * c["lc_touches"] + 64 * c["mc_updates_accepted"],
         "mq_apply_kernel": 128 * c["mc_updates_accepted"],
     }
     B = algorithmic_bytes(c, local_pixels)
@@ -197,6 +199,7 @@ def main():
                 "frame": {"algorithmic_bytes": int(B), "render_ms": round(pipeline_ms, 4), "achieved": round(B / (pipeline_ms * 1e-3) / 1e9, 1),
                           "frac": round(B / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": round(B / max(1, local_pixels * args.spp), 1)},
                 "kernels_ms_per_frame": {k: round(v, 4) for k, v in kms.items()},
+                "launches_ms": [[round(a / n_timed, 4), round(b / n_timed, 4)] for a, b in per_round[:rounds + 1]],  # [trace, shade] per round; entry 0 = primary
                 "kernels_algorithmic_bytes_per_frame": {k: int(v) for k, v in kbytes.items()}, "counters": c}
 
     out = {"metric": "Msamples/s at 1920x1080 1spp (ad_sepulcher); per-pixel L2 vs reference", "value": round(value, 3),

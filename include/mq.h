@@ -179,10 +179,18 @@ int mq_timing_reset(mq_ctx* ctx);
 int mq_timing_get(mq_ctx* ctx, uint32_t* frames, double* render_ms_sum, double* update_ms_sum);
 /* the render time split by kernel class: primary (first hit), trace (BVH traversal of bounce rays), bounce (shading/guiding) */
 int mq_timing_get_detail(mq_ctx* ctx, double* primary_ms_sum, double* trace_ms_sum, double* bounce_ms_sum);
+/* per launch: entry 0 = (trace of the primary rays, first-hit shading), entry 1 + r = (trace, bounce) of
+ * round r; at most MQ_TIMING_ROUNDS entries.  Sums over the frames since the last reset. */
+#define MQ_TIMING_ROUNDS 9
+int mq_timing_get_rounds(mq_ctx* ctx, double* trace_ms_sum, double* shade_ms_sum, int n);
 /* enable work counting for subsequent frames (separate kernel instantiation, slower) */
 int mq_enable_counters(mq_ctx* ctx, int on);
 int mq_get_counters(mq_ctx* ctx, mq_counters* out);
 int mq_reset_state(mq_ctx* ctx); /* next process() behaves like iteration 0 */
+/* Profiling builds (-DMQ_PROF) only: shader clocks per kernel code section, summed over all waves
+ * since the last reset; all zero in a product build.  Section ids: tools/prof_sections.py. */
+#define MQ_PROF_SECTION_COUNT 32
+int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 
 /* ---- multi-GPU framebuffer sharding (no reference counterpart) ----
  * Rank r of `world` renders the 8x8-pixel tiles t with t % world == r into MQ_OUT_TILES

@@ -26,6 +26,8 @@ int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F,
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s);
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s);
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+int mq_stack_lds_entries();
+int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int out[3]);
 int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
 int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s);
@@ -55,7 +57,7 @@ struct mq_ctx {
     float sah_cost = 0.0f;
     bool committed = false;
     // device scene
-    DevBuf d_nodes, d_tris, d_texdesc, d_texels, d_lut;
+    DevBuf d_nodes, d_tris, d_shade, d_texdesc, d_texels, d_lut;
     DevBuf d_ext[MQ_MAX_GEOMETRIES], d_idx[MQ_MAX_GEOMETRIES], d_prev[MQ_MAX_GEOMETRIES];
     MqSceneDev scene{};
     // frame state
@@ -76,11 +78,14 @@ struct mq_ctx {
     MqParams params{};
     bool count_enabled = false;
     int cu_count = 0, grid_blocks = 0;
+    int grid_frame[3] = {0, 0, 0}; // primary, trace, bounce: every block resident (see frame_grids)
+    int grid_key = -1;             // lds_rows2 the grids were derived for
     static const int EV_RING = 32;
-    static const int EV_PER = 3 + 2 * 8; // start, primary end, (trace end, bounce end) x up to 8 rounds, apply end
+    static const int EV_PER = 4 + 2 * 8; // start, primary trace end, primary shade end, (trace end, bounce end) x up to 8 rounds, apply end
     hipEvent_t evr[EV_RING][EV_PER] = {};
     int ev_rounds[EV_RING] = {};
     double t_primary_sum = 0.0, t_trace_sum = 0.0, t_bounce_sum = 0.0;
+    double t_round_trace[MQ_TIMING_ROUNDS] = {}, t_round_shade[MQ_TIMING_ROUNDS] = {};
     bool ev_pending[EV_RING] = {};
     int ev_slot = 0, ev_last = -1;
     double t_render_sum = 0.0, t_update_sum = 0.0; uint32_t t_frames = 0;
@@ -288,7 +293,7 @@ void free_frame_state(mq_ctx* c) {
     c->connected = false;
 }
 void free_scene_dev(mq_ctx* c) {
-    dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_texdesc); dev_free(c->d_texels); dev_free(c->d_lut);
+    dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels); dev_free(c->d_lut);
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
 }
 
@@ -541,11 +546,25 @@ int mq_scene_commit(mq_ctx* c) {
         memcpy(&pool[at], tx.px.data(), n * 4);
     }
     if ((r = dev_upload(c, c->d_texdesc, desc.data(), desc.size() * sizeof(MqTexDesc)))) return r;
+    { // shading records in BVH triangle order
+        std::vector<MqShadeRec> recs(c->tris.size());
+        for (size_t i = 0; i < c->tris.size(); i++) {
+            const uint32_t key = c->tris[i].key;
+            const mq_ext& e = c->geo[key >> 28].ext[key & 0x0fffffffu];
+            MqShadeRec& q = recs[i]; memset(&q, 0, sizeof q);
+            static_assert(sizeof(mq_ext) == 28, "extra data is 7 dwords");
+            memcpy(q.ext, &e, 28);
+            q.albedo = desc[std::min<uint32_t>(e.texnum_alpha & 0xfffu, MQ_MAX_GLTEXTURES - 1)];
+            const uint32_t fb = e.texnum_fb_flags & 0xfffu;
+            if (fb < MQ_MAX_GLTEXTURES) q.fb = desc[fb]; else { q.fb.offset = MQ_NIL; }
+        }
+        if ((r = dev_upload(c, c->d_shade, recs.data(), recs.size() * sizeof(MqShadeRec)))) return r;
+    }
     if ((r = dev_upload(c, c->d_texels, pool.data(), pool.size() * 4))) return r;
     float lut[256];
     for (int i = 0; i < 256; i++) { double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4)); }
     if ((r = dev_upload(c, c->d_lut, lut, sizeof lut))) return r;
-    c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p;
+    c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p; c->scene.shade = (const MqShadeRec*)c->d_shade.p;
     c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const uint32_t*)c->d_texels.p; c->scene.srgb_lut = (const float*)c->d_lut.p;
     c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
     return MQ_OK;
@@ -623,15 +642,17 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
 
 static int drain_slot(mq_ctx* c, int slot) {
     if (!c->ev_pending[slot]) return MQ_OK;
-    const int R = c->ev_rounds[slot], last = 2 + 2 * R;
+    const int R = c->ev_rounds[slot], last = 3 + 2 * R;
     HIPCHK(c, hipEventSynchronize(c->evr[slot][last]));
     float prim = 0, tr = 0, bo = 0, ap = 0, x = 0;
-    HIPCHK(c, hipEventElapsedTime(&prim, c->evr[slot][0], c->evr[slot][1]));
+    HIPCHK(c, hipEventElapsedTime(&tr, c->evr[slot][0], c->evr[slot][1]));   // no separate primary-ray launch: ~0
+    HIPCHK(c, hipEventElapsedTime(&prim, c->evr[slot][1], c->evr[slot][2]));
+    c->t_round_trace[0] += tr; c->t_round_shade[0] += prim;
     for (int k = 0; k < R; k++) {
-        HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][1 + 2 * k], c->evr[slot][2 + 2 * k])); tr += x;
-        HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][2 + 2 * k], c->evr[slot][3 + 2 * k])); bo += x;
+        HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][2 + 2 * k], c->evr[slot][3 + 2 * k])); tr += x; c->t_round_trace[1 + k] += x;
+        HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][3 + 2 * k], c->evr[slot][4 + 2 * k])); bo += x; c->t_round_shade[1 + k] += x;
     }
-    HIPCHK(c, hipEventElapsedTime(&ap, c->evr[slot][1 + 2 * R], c->evr[slot][last]));
+    HIPCHK(c, hipEventElapsedTime(&ap, c->evr[slot][2 + 2 * R], c->evr[slot][last]));
     c->t_primary_sum += prim; c->t_trace_sum += tr; c->t_bounce_sum += bo;
     c->t_render_sum += prim + tr + bo; c->t_update_sum += ap; c->t_frames++;
     if (slot == c->ev_last) { c->last_render_ms = prim + tr + bo; c->last_update_ms = ap; }
@@ -655,6 +676,33 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p; F.ray_cap = c->ray_cap;
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
     F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
+    const int K = c->params.reference_mode ? 0 : std::max(0, c->params.mc_samples);
+    F.lds_rows2 = (uint32_t)std::max(mq_stack_lds_entries(), (6 * K + 1) / 2);
+}
+
+#ifndef MQ_GRID_MODE
+#define MQ_GRID_MODE 1
+#endif
+// Grid sizes of the three frame kernels.  They are grid-stride / persistent kernels, so the right
+// grid is exactly the number of blocks the chip holds at once (CUs x resident blocks per CU at the
+// kernel's register and LDS footprint): a larger grid runs as a ragged last wave of blocks.
+static int frame_grids(mq_ctx* c, const MqFrame& F) {
+    const int key = (int)F.lds_rows2 * 2 + (c->params.reference_mode ? 1 : 0);
+    if (c->grid_key == key) return MQ_OK;
+    int occ[3] = {0, 0, 0};
+    int e = mq_resident_blocks(!c->params.reference_mode, (size_t)F.lds_rows2 * 64 * 8 * (mq_render_block_size() / 64), occ);
+    if (e) return fail(c, MQ_EHIP, std::string("occupancy query: ") + hipGetErrorString((hipError_t)e));
+    for (int i = 0; i < 3; i++) {
+#if MQ_GRID_MODE == 0
+        c->grid_frame[i] = c->grid_blocks;
+#else
+        c->grid_frame[i] = std::min(c->grid_blocks, std::max(1, c->cu_count) * std::max(1, occ[i]));
+#endif
+        static const char* const names[3] = {"MQ_DEBUG_PRIMARY_BLOCKS_PER_CU", "MQ_DEBUG_TRACE_BLOCKS_PER_CU", "MQ_DEBUG_BOUNCE_BLOCKS_PER_CU"};
+        if (const char* ev = getenv(names[i])) { int v = atoi(ev); if (v > 0) c->grid_frame[i] = std::min(c->grid_blocks, std::max(1, c->cu_count) * v); } // tuning experiments only
+    }
+    c->grid_key = key;
+    return MQ_OK;
 }
 
 int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
@@ -667,6 +715,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->params_dirty) props_to_params(c);
     MqFrame F; fill_frame(c, u, F);
+    { int r = frame_grids(c, F); if (r) return r; }
     if (c->iteration == 0) { // render_mcpg.cpp:221-226
         HIPCHK(c, hipMemsetAsync(c->d_mc.p, 0, c->d_mc.bytes, s));
         HIPCHK(c, hipMemsetAsync(c->d_lc.p, 0, c->d_lc.bytes, s));
@@ -683,7 +732,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         return MQ_OK;
     }
     HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_QUEUE0, 0, (MQ_CTRL_WORDS - MQ_CTRL_QUEUE0) * 4, s)); // queue counters; the update tail survives (volume-pass entries of the last frame)
-    if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(MqCountersDev), s));
+    if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, offsetof(MqCountersDev, prof), s));
     const bool guided = !c->params.reference_mode;
     // rounds: every sample needs at most (max_path_length - 1) traced segments, render_mcpg.cpp:142-143
     const int rounds = std::max(0, c->params.spp) * std::max(0, c->params.max_path_length - 1);
@@ -694,16 +743,17 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     { int r = drain_slot(c, slot); if (r) return r; } // the slot's previous frame finished long ago
     hipEvent_t* ev = c->evr[slot];
     HIPCHK(c, hipEventRecord(ev[0], s));
-    int e = mq_launch_primary(c->scene, c->params, F, guided, c->count_enabled, c->grid_blocks, s);
+    HIPCHK(c, hipEventRecord(ev[1], s)); // (slot of a separate primary-ray trace launch: none, the primary kernel traces its own rays)
+    int e = mq_launch_primary(c->scene, c->params, F, guided, c->count_enabled, c->grid_frame[0], s);
     if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
-    HIPCHK(c, hipEventRecord(ev[1], s));
+    HIPCHK(c, hipEventRecord(ev[2], s));
     for (int r = 0; r < rounds; r++) {
-        e = mq_launch_trace_queue(c->scene, F, r, c->count_enabled, c->grid_blocks, s);
+        e = mq_launch_trace_queue(c->scene, F, r, c->count_enabled, c->grid_frame[1], s);
         if (e) return fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e));
-        if (r < timed) HIPCHK(c, hipEventRecord(ev[2 + 2 * r], s));
-        e = mq_launch_bounce(c->scene, c->params, F, r, guided, c->count_enabled, c->grid_blocks, s);
-        if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
         if (r < timed) HIPCHK(c, hipEventRecord(ev[3 + 2 * r], s));
+        e = mq_launch_bounce(c->scene, c->params, F, r, guided, c->count_enabled, c->grid_frame[2], s);
+        if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
+        if (r < timed) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s));
     }
     if (guided) { // render_mcpg.cpp:261-277
         e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, s);
@@ -729,7 +779,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         e = mq_launch_volume_finish(c->params, F, c->grid_blocks, s);
         if (e) return fail(c, MQ_EHIP, std::string("volume finish launch: ") + hipGetErrorString((hipError_t)e));
     } else HIPCHK(c, hipMemsetAsync(c->d_out[MQ_OUT_VOLUME].p, 0, c->d_out[MQ_OUT_VOLUME].bytes, s));
-    HIPCHK(c, hipEventRecord(ev[2 + 2 * timed], s));
+    HIPCHK(c, hipEventRecord(ev[3 + 2 * timed], s));
     c->ev_rounds[slot] = timed;
     c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
     c->ev_valid = true;
@@ -773,6 +823,7 @@ int mq_timing_reset(mq_ctx* c) {
     for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
     c->t_render_sum = c->t_update_sum = 0.0; c->t_frames = 0;
     c->t_primary_sum = c->t_trace_sum = c->t_bounce_sum = 0.0;
+    for (int i = 0; i < MQ_TIMING_ROUNDS; i++) c->t_round_trace[i] = c->t_round_shade[i] = 0.0;
     return MQ_OK;
 }
 int mq_timing_get(mq_ctx* c, uint32_t* frames, double* render_ms_sum, double* update_ms_sum) {
@@ -787,6 +838,13 @@ int mq_timing_get_detail(mq_ctx* c, double* primary_ms_sum, double* trace_ms_sum
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
     for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
     if (primary_ms_sum) *primary_ms_sum = c->t_primary_sum; if (trace_ms_sum) *trace_ms_sum = c->t_trace_sum; if (bounce_ms_sum) *bounce_ms_sum = c->t_bounce_sum;
+    return MQ_OK;
+}
+int mq_timing_get_rounds(mq_ctx* c, double* trace_ms_sum, double* shade_ms_sum, int n) {
+    if (!c || n < 0) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
+    for (int i = 0; i < n && i < MQ_TIMING_ROUNDS; i++) { if (trace_ms_sum) trace_ms_sum[i] = c->t_round_trace[i]; if (shade_ms_sum) shade_ms_sum[i] = c->t_round_shade[i]; }
     return MQ_OK;
 }
 int mq_enable_counters(mq_ctx* c, int on) { if (!c) return MQ_EINVAL; c->count_enabled = on != 0; return MQ_OK; }
@@ -805,6 +863,20 @@ int mq_get_counters(mq_ctx* c, mq_counters* out) {
     uint32_t flag = 0;
     HIPCHK(c, hipMemcpy(&flag, c->d_ctrl.p, 4, hipMemcpyDeviceToHost));
     out->queue_overflow = flag;
+    return MQ_OK;
+}
+
+int mq_debug_section_clocks(mq_ctx* c, uint64_t* out, int n, int reset) {
+    if (!c || !out || n < 0) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->d_counters.p) return fail(c, MQ_ESTATE, "not connected");
+    static_assert(MQ_PROF_SECTION_COUNT == MQ_PROF_SECTIONS, "section count");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    MqCountersDev d;
+    HIPCHK(c, hipMemcpy(&d, c->d_counters.p, sizeof d, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < MQ_PROF_SECTIONS; i++) out[i] = d.prof[i];
+    if (reset) HIPCHK(c, hipMemset((char*)c->d_counters.p + offsetof(MqCountersDev, prof), 0, sizeof d.prof));
     return MQ_OK;
 }
 

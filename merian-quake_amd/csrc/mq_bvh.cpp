@@ -27,6 +27,10 @@ struct AABB {
     }
 };
 
+// most triangles per leaf of the binary tree (a compressed child slot addresses up to 3)
+#ifndef MQ_BVH_LEAF
+#define MQ_BVH_LEAF 3
+#endif
 struct BNode { AABB box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
 
 struct Builder {
@@ -45,7 +49,7 @@ struct Builder {
         AABB cbox; cbox.reset();
         for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[order[i]]); cbox.grow(&cent[3 * order[i]]); }
         nodes[id].box = box;
-        if (count <= 3) { nodes[id].first = first; nodes[id].count = count; return id; }
+        if (count <= MQ_BVH_LEAF) { nodes[id].first = first; nodes[id].count = count; return id; }
         // binned SAH over the three axes, 16 bins
         const int NB = 16;
         int best_axis = -1, best_split = 0; float best_cost = INFINITY;

@@ -22,8 +22,9 @@
 #define MQ_STACK_LDS 12
 #endif
 #define MQ_SPILL_ENTRIES (64 - MQ_STACK_LDS)
-// per-wave LDS region of the primary kernel in uint2 rows: max(stack entries, 6 floats x MQ_MAX_MC_SAMPLES lobes / 2)
-#define MQ_LDS_DWORDS2 ((6 * MQ_MAX_MC_SAMPLES + 1) / 2 > MQ_STACK_LDS ? (6 * MQ_MAX_MC_SAMPLES + 1) / 2 : MQ_STACK_LDS)
+// The shading kernels take their LDS dynamically: F.lds_rows2 rows of 64 x 8 bytes per wave, sized by the
+// host from the run-time sample count K (3 rows per Markov-chain sample; the primary kernel's
+// traversal stack shares the region), so that K = 5 costs 30 KB per block instead of the 48 KB of K = 8.
 #ifndef MQ_OCC_SHADE
 #define MQ_OCC_SHADE 2
 #endif
@@ -43,7 +44,28 @@ struct Hit { // res/shader/hit.glsl.h:6-17
 // position of entry k of shard `shard` in a sharded queue (see "sharded queues" below)
 MQ_DEV uint32_t shard_pos(uint32_t shard, uint32_t k) { return (((k >> 6) * MQ_SHARDS + shard) << 6) | (k & 63u); }
 
-struct Ctr { uint32_t rays, nodes, tris, segments, guided, lc, upd_ok, upd_drop, mc_reads, pixels, lc_ok, lc_cancel; };
+struct Ctr {
+    uint32_t rays, nodes, tris, segments, guided, lc, upd_ok, upd_drop, mc_reads, pixels, lc_ok, lc_cancel;
+#ifdef MQ_PROF
+    uint32_t pt, prof[MQ_PROF_SECTIONS];
+#endif
+};
+// Lap profiling (-DMQ_PROF builds only): PLAP(ctr, i) charges the shader clocks since the previous
+// lap of this wave to section i.  Sections: see tools/prof_sections.py.
+#ifdef MQ_PROF
+MQ_DEV void prof_lap(Ctr& c, int i) { uint32_t t = (uint32_t)__builtin_readcyclecounter(); c.prof[i] += t - c.pt; c.pt = t; }
+MQ_DEV void prof_start(Ctr& c) { c.pt = (uint32_t)__builtin_readcyclecounter(); }
+MQ_DEV void prof_flush(MqCountersDev* g, const Ctr& c) {
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < MQ_PROF_SECTIONS; i++) if (c.prof[i]) atomicAdd(&g->prof[i], (unsigned long long)c.prof[i]);
+}
+#define PLAP(c, i) prof_lap(c, i)
+#define PSTART(c) prof_start(c)
+#define PFLUSH(g, c) prof_flush(g, c)
+#else
+#define PLAP(c, i)
+#define PSTART(c)
+#define PFLUSH(g, c)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // textures: RGBA8 texel pool, REPEAT wrap, nearest or bilinear, sRGB decode through a LUT
@@ -74,9 +96,7 @@ MQ_DEV void tex_linear_coord(float s, float fw, int w, int& i0, int& i1, float& 
     if (b >= w) b -= w;
     i0 = a; i1 = b;
 }
-MQ_DEV f4 tex_sample(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
-    if (texnum > MQ_MAX_GLTEXTURES - 1) texnum = MQ_MAX_GLTEXTURES - 1;
-    MqTexDesc tx = sc.tex[texnum];
+MQ_DEV f4 tex_sample_desc(const MqSceneDev& sc, const MqTexDesc& tx, float s, float t) {
     if (tx.offset == MQ_NIL) { f4 g; g.r = g.g = g.b = 0.5f; g.a = 1.0f; return g; }
     float fw = (float)tx.w, fh = (float)tx.h;
     if (!(tx.flags & MQ_TEX_LINEAR)) return texel(sc, tx, tex_nearest_coord(s, fw, (int)tx.w), tex_nearest_coord(t, fh, (int)tx.h));
@@ -91,9 +111,11 @@ MQ_DEV f4 tex_sample(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
     r.a = mmix(mmix(a.a, b.a, fx), mmix(d.a, e.a, fx), fy);
     return r;
 }
-MQ_DEV float tex_gather_alpha_r(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
+MQ_DEV f4 tex_sample(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
     if (texnum > MQ_MAX_GLTEXTURES - 1) texnum = MQ_MAX_GLTEXTURES - 1;
-    MqTexDesc tx = sc.tex[texnum];
+    return tex_sample_desc(sc, sc.tex[texnum], s, t);
+}
+MQ_DEV float tex_gather_alpha_r(const MqSceneDev& sc, const MqTexDesc& tx, float s, float t) {
     if (tx.offset == MQ_NIL) return 1.0f;
     int x0, x1, y0, y1; float fx, fy;
     tex_linear_coord(s, (float)tx.w, (int)tx.w, x0, x1, fx);
@@ -101,25 +123,33 @@ MQ_DEV float tex_gather_alpha_r(const MqSceneDev& sc, uint32_t texnum, float s, 
     return texel(sc, tx, x0, y1).a;
 }
 
-MQ_DEV mq_ext load_ext(const MqSceneDev& sc, uint32_t key) {
-    // 28-byte records are 4-byte aligned: 7 dword loads
-    const uint32_t* p = (const uint32_t*)(sc.geo[key >> 28].ext + (key & 0x0fffffffu));
+
+// shading record of BVH triangle `tri`: extra data + resolved texture descriptors, four 16-byte loads
+MQ_DEV MqTexDesc desc_from(uint32_t a, uint32_t b, uint32_t c) { MqTexDesc d; d.offset = a; d.w = (uint16_t)(b & 0xffffu); d.h = (uint16_t)(b >> 16); d.flags = c; return d; }
+MQ_DEV void load_shade(const MqSceneDev& sc, uint32_t tri, mq_ext& e, MqTexDesc& albedo, MqTexDesc& fb) {
+    const uint4* p = (const uint4*)(sc.shade + tri);
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
     union { mq_ext e; uint32_t w[7]; } u;
-#pragma unroll
-    for (int i = 0; i < 7; i++) u.w[i] = p[i];
-    return u.e;
+    u.w[0] = a.x; u.w[1] = a.y; u.w[2] = a.z; u.w[3] = a.w; u.w[4] = b.x; u.w[5] = b.y; u.w[6] = b.z;
+    e = u.e;
+    albedo = desc_from(c.x, c.y, c.z);
+    fb = desc_from(d.x, d.y, d.z);
 }
 
 // any-hit confirmation, raytrace.glsl:100-118
-MQ_DEV bool anyhit_confirm(const MqSceneDev& sc, uint32_t key, float u, float v) {
-    mq_ext e = load_ext(sc, key);
+MQ_DEV bool anyhit_confirm(const MqSceneDev& sc, uint32_t tri, float u, float v) {
+    const uint4* p = (const uint4*)(sc.shade + tri);
+    const uint4 a = p[0], b = p[1], c = p[2];
+    union { mq_ext e; uint32_t w[7]; } x;
+    x.w[0] = a.x; x.w[1] = a.y; x.w[2] = a.z; x.w[3] = a.w; x.w[4] = b.x; x.w[5] = b.y; x.w[6] = b.z;
+    const mq_ext& e = x.e;
     uint32_t flags = e.texnum_fb_flags >> 12, alpha = e.texnum_alpha >> 12;
     if (flags > 0 && flags < 7) return true;
     if (alpha != 0) return rh((float)(alpha - 1) / 14.0f) >= MQ_ALPHA_THRESHOLD;
     float b0 = 1.0f - u - v;
     float s = h2f(e.st[0]) * b0 + h2f(e.st[2]) * u + h2f(e.st[4]) * v;
     float t = h2f(e.st[1]) * b0 + h2f(e.st[3]) * u + h2f(e.st[5]) * v;
-    return tex_gather_alpha_r(sc, e.texnum_alpha & 0xfffu, s, t) >= MQ_ALPHA_THRESHOLD;
+    return tex_gather_alpha_r(sc, desc_from(c.x, c.y, c.z), s, t) >= MQ_ALPHA_THRESHOLD;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -146,25 +176,29 @@ MQ_DEV bool tri_isect(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float& t, float& u, float
     return true;
 }
 
-MQ_DEV float ub(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
-
-// One group of four children: bytes of nq/fq hold near/far quantised planes per axis.
+// One group of four children: bytes of nq/fq hold near/far quantised planes per axis.  The slab
+// distances of two children are evaluated per instruction (v_pk_fma_f32, one rounding per product-sum
+// exactly like fmaf), and the per-child meta bytes (child bits << 5 | bit index, CWBVH paper sect. 4)
+// are decoded for all four children at once with byte-parallel integer arithmetic.  An empty child
+// has meta 0 and contributes no bits whatever its box test says.
+typedef float v2f __attribute__((ext_vector_type(2)));
+MQ_DEV v2f ub2(uint32_t w, int k) { v2f r; r.x = (float)((w >> (8 * k)) & 0xffu); r.y = (float)((w >> (8 * k + 8)) & 0xffu); return r; }
 MQ_DEV uint32_t box4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, uint32_t meta,
-                     float adx, float ady, float adz, float ox, float oy, float oz, float tlim, uint32_t octinv) {
+                     float adx, float ady, float adz, float ox, float oy, float oz, float tlim, uint32_t oct4) {
+    const uint32_t inner = ((meta & (meta << 1)) & 0x10101010u) >> 4;      // 1 per byte whose meta has (m & 0x18) == 0x18
+    const uint32_t bit4 = (meta ^ (oct4 & ((inner << 8) - inner))) & 0x1f1f1f1fu; // bit index per child, octant-relative for inner nodes (x * 255 as shift - x: full rate)
+    const uint32_t cb4 = (meta >> 5) & 0x07070707u;                        // child bits per child
+    const v2f ax = {adx, adx}, ay = {ady, ady}, az = {adz, adz}, bx = {ox, ox}, by = {oy, oy}, bz = {oz, oz};
     uint32_t mask = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float tnx = __builtin_fmaf(ub(nx, j), adx, ox), tfx = __builtin_fmaf(ub(fx, j), adx, ox);
-        float tny = __builtin_fmaf(ub(ny, j), ady, oy), tfy = __builtin_fmaf(ub(fy, j), ady, oy);
-        float tnz = __builtin_fmaf(ub(nz, j), adz, oz), tfz = __builtin_fmaf(ub(fz, j), adz, oz);
-        float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        float tf = fminf(fminf(tfx, tfy), fminf(tfz, tlim));
-        uint32_t m = (meta >> (8 * j)) & 0xffu;
-        if (m != 0 && tn <= tf) {
-            uint32_t inner = (m & 0x18u) == 0x18u ? 1u : 0u;
-            uint32_t bit = (m & 31u) ^ (inner ? octinv : 0u);
-            mask |= (m >> 5) << bit;
-        }
+    for (int j = 0; j < 4; j += 2) {
+        v2f tnx = __builtin_elementwise_fma(ub2(nx, j), ax, bx), tfx = __builtin_elementwise_fma(ub2(fx, j), ax, bx);
+        v2f tny = __builtin_elementwise_fma(ub2(ny, j), ay, by), tfy = __builtin_elementwise_fma(ub2(fy, j), ay, by);
+        v2f tnz = __builtin_elementwise_fma(ub2(nz, j), az, bz), tfz = __builtin_elementwise_fma(ub2(fz, j), az, bz);
+        float tn0 = fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, 0.0f)), tf0 = fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, tlim));
+        float tn1 = fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, 0.0f)), tf1 = fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, tlim));
+        if (tn0 <= tf0) mask |= ((cb4 >> (8 * j)) & 0xffu) << ((bit4 >> (8 * j)) & 0xffu);
+        if (tn1 <= tf1) mask |= ((cb4 >> (8 * j + 8)) & 0xffu) << ((bit4 >> (8 * j + 8)) & 0xffu);
     }
     return mask;
 }
@@ -225,8 +259,15 @@ MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane]
     uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
     uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
     uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
-    uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, t.octinv) |
-                  box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, t.octinv);
+    uint32_t oct4 = t.octinv | (t.octinv << 8); oct4 |= oct4 << 16; // octinv in every byte
+    uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, oct4) |
+                  box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, oct4);
+#ifdef MQ_EXP_DUMMY_VALU // experiment: extra dependent VALU work per node visit (is the kernel issue bound?)
+    { float z = adx; for (int i = 0; i < MQ_EXP_DUMMY_VALU; i++) z = __builtin_fmaf(z, ady, adz); if (z == 123.456f) hm ^= 1u; }
+#endif
+#ifdef MQ_EXP_DUMMY_LOAD // experiment: extra 16-byte gathers per node visit (is the kernel L1 bound?)
+    { uint32_t acc = 0; for (int i = 0; i < MQ_EXP_DUMMY_LOAD; i++) { uint4 x = ((const uint4*)(sc.nodes + ((G.x + rel + 977u * (i + 1)) % sc.n_nodes)))[i % 5]; acc ^= x.x; } if (acc == 0x12345678u) hm ^= 1u; }
+#endif
     G.x = n1.x;
     G.y = (hm & 0xff000000u) | (n0.w >> 24);
     t.G = G;
@@ -239,15 +280,18 @@ template <bool COUNT>
 MQ_DEV void trav_tri(const MqSceneDev& sc, Trav& t, Ctr& ctr) {
     uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
     t.tmask &= t.tmask - 1u;
-    const uint4* tp = (const uint4*)(sc.tris + (t.tbase + k));
-    uint4 a = tp[0], b = tp[1], c = tp[2];
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    const u4v* tp = (const u4v*)(sc.tris + (t.tbase + k));
+    u4v a = tp[0], b = tp[1], c = tp[2];
+    // keep the record as three 16-byte loads (the vectoriser otherwise re-slices it into four overlapping ones)
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
     if (COUNT) ctr.tris++;
     float tt = 0.0f, u = 0.0f, v = 0.0f;
     bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
                             F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
                             F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), tt, u, v);
     accept = accept && (tt < t.tmax) && (tt < t.hit.t || (tt == t.hit.t && c.y < t.best_key));
-    if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, c.y, u, v);
+    if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, t.tbase + k, u, v);
     if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = t.tbase + k; t.best_key = c.y; }
 }
 
@@ -326,16 +370,17 @@ MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform&
     uint32_t key = 0, tflags = 0;
     f3 p0, p1, p2;
     mq_ext e;
+    MqTexDesc tx_albedo, tx_fb;
     uint32_t flags = 0;
     bool have = rhit.tri != MQ_NIL;
     if (have) {
         const uint4* tp = (const uint4*)(sc.tris + rhit.tri);
         uint4 a = tp[0], b = tp[1], c = tp[2];
+        load_shade(sc, rhit.tri, e, tx_albedo, tx_fb); // independent of the triangle fetch: both go out together
         p0 = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
         p1 = F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
         p2 = F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
         key = c.y; tflags = c.z;
-        e = load_ext(sc, key);
         flags = e.texnum_fb_flags >> 12;
     }
     if (!have || flags == MQ_MAT_FLAGS_SKY) { // :170-194
@@ -369,7 +414,7 @@ MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform&
         uint32_t i0 = g.idx[3 * prim], i1 = g.idx[3 * prim + 1], i2 = g.idx[3 * prim + 2];
         hit.prev_pos = (ld3(g.prev_vtx, i0) * b0 + ld3(g.prev_vtx, i1) * b1) + ld3(g.prev_vtx, i2) * b2;
     } else hit.prev_pos = hit.pos;
-    f4 at = tex_sample(sc, e.texnum_alpha & 0xfffu, s, t);
+    f4 at = tex_sample_desc(sc, tx_albedo, s, t);
     f3 albedo_tex = rh3(F3(mq_pow(rh(at.r), 1.0f / 1.2f), mq_pow(rh(at.g), 1.0f / 1.2f), mq_pow(rh(at.b), 1.0f / 1.2f)));
     if (e.n1_brush == 0xffffffffu) { // :249-274
         uint32_t tn_norm = e.n0_gloss_norm >> 16, tn_gloss = e.n0_gloss_norm & 0xffffu;
@@ -406,7 +451,7 @@ MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform&
         uint32_t fb = e.texnum_fb_flags & 0xfffu;
         hit.albedo = albedo_tex;
         if (fb > 0 && fb < MQ_MAX_GLTEXTURES) {
-            f4 ft = tex_sample(sc, fb, s, t);
+            f4 ft = tex_sample_desc(sc, tx_fb, s, t);
             f3 em = ldr_to_hdr(rh3(F3(ft.r, ft.g, ft.b)));
             if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {
                 contribution = rh3(contribution + rh3(throughput * em));
@@ -586,32 +631,34 @@ MQ_DEV void load_chit(const uint32_t* src, Hit& h) { // hit.glsl.h:45-53
 MQ_DEV void enqueue_update(const MqParams& P, const MqFrame& F, uint32_t& rng, uint32_t index, uint32_t id, f3 pos, float w, f3 target, f3 target_mv, f3 normal, Ctr& ctr) {
     const mq_uniform& U = F.u;
     if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, rng, pos, normal, index, h16); }
-    // Soft cap: a slot that already holds MQ_MAX_UPDATES entries this frame takes no more
-    // (mc.glsl:169-184).  The count is read past L1 and bumped without waiting for the result, so only
-    // one memory round trip sits on the path; racing lanes may overshoot by a few entries and the
-    // update pass enforces the exact cap on arrival order.
-    uint32_t cnt = __hip_atomic_load(&F.upd_count[index], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cnt < MQ_MAX_UPDATES) {
-        __hip_atomic_fetch_add(&F.upd_count[index], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t uq = 0;
-        { // wave-aggregated append to this wave's shard of the update queue (lanes arrive here divergently)
-            unsigned long long m = __ballot(1);
-            const int lane = threadIdx.x & 63;
-            const uint32_t shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MQ_SHARDS - 1);
-            int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES + shard * MQ_SHARD_STRIDE], (uint32_t)__popcll(m));
-            base = __shfl(base, leader, 64);
-            uq = shard_pos(shard, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-        }
-        if (uq < F.queue_cap) {
-            uint4* e = (uint4*)(F.queue + uq);
+    // Cap (mc.glsl:169-184): the returning increment of the slot's counter is this update's arrival
+    // rank; ranks >= MQ_MAX_UPDATES are dropped.  The queue position is allocated at the same time
+    // (wave-aggregated append to this wave's shard), so the two atomics overlap and only ONE memory
+    // round trip sits on the path; a dropped update leaves a 16-byte "no slot" marker in its position.
+    uint32_t uq = 0, rank_in_slot = 0;
+    {
+        unsigned long long m = __ballot(1); // lanes arrive here divergently
+        const int lane = threadIdx.x & 63;
+        const uint32_t shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MQ_SHARDS - 1);
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&F.ctrl[MQ_CTRL_UPDATES + shard * MQ_SHARD_STRIDE], (uint32_t)__popcll(m));
+        rank_in_slot = atomicAdd(&F.upd_count[index], 1u);
+        base = __shfl(base, leader, 64);
+        uq = shard_pos(shard, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+    }
+    if (uq < F.queue_cap) {
+        uint4* e = (uint4*)(F.queue + uq);
+        if (rank_in_slot < MQ_MAX_UPDATES) {
             e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(w));
             e[1] = make_uint4(__float_as_uint(target.x), __float_as_uint(target.y), __float_as_uint(target.z), id);
             e[2] = make_uint4(__float_as_uint(normal.x), __float_as_uint(normal.y), __float_as_uint(normal.z), __float_as_uint(U.cl_time));
             e[3] = make_uint4((uint32_t)f2h(target_mv.x) | ((uint32_t)f2h(target_mv.y) << 16), (uint32_t)f2h(target_mv.z), index, 0u);
+        } else {
+            e[3] = make_uint4(0u, 0u, MQ_NIL, 0u);
+            ctr.upd_drop++;
         }
-    } else ctr.upd_drop++;
+    }
 }
 
 struct Path {
@@ -676,6 +723,7 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
         if (need_dir) {
             need_dir = false;
             if (COUNT) ctr.segments++;
+            PLAP(ctr, 4);
             const float alpha = roughness_to_alpha(p.cur.roughness);
             f3 wo;
             bool rejected = false;
@@ -720,6 +768,7 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                         lobes[0] = st.sum_w; lobes[64] = d.x; lobes[128] = d.y; lobes[192] = d.z; lobes[256] = kk; lobes[320] = nrm;
                     } else { li[0] = st.sum_w; li[64] = d.x; li[128] = d.y; li[192] = d.z; li[256] = kk; li[320] = nrm; }
                 }
+                PLAP(ctr, 5);
                 if (p.score_sum == 0.0f || xorshift(p.rng) < P.surf_bsdf_p) { // :113-117
                     float x0 = xorshift(p.rng), x1 = xorshift(p.rng), x2 = xorshift(p.rng);
                     wo = bsdf_sample(p.cur.wi, p.cur.normal, alpha, x0, x1, x2);
@@ -729,6 +778,7 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                     float x0 = xorshift(p.rng), x1 = xorshift(p.rng);
                     wo = vmf_sample(F3(lobes[64], lobes[128], lobes[192]), lobes[256], x0, x1);
                 }
+                PLAP(ctr, 6);
                 p.wodotn = dot(wo, p.cur.normal);
                 if (p.wodotn <= 1e-3f || dot(wo, decode_normal(p.cur.enc_geonormal)) <= 1e-3f) rejected = true;
                 else {
@@ -748,10 +798,12 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                     if (p.mc_index != MQ_NIL) p.lm_dir_ok = !(dot(wo, mc_state_dir(sel, p.cur.pos)) < 0.9f + 0.1f * mc_state_mean_cos(P, sel, p.cur.pos));
                 }
             }
+            PLAP(ctr, 7);
             if (rejected) sample_done = true; // `break` at mcpg.comp:63 / :125
             else {
                 p.bsdf = bsdf_times_wodotn(p.cur.wi, wo, p.cur.normal, alpha, 0.02f); // :153 (pre-trace data only)
                 p.wo = wo;
+                PLAP(ctr, 8);
                 return true;
             }
         }
@@ -828,11 +880,14 @@ MQ_DEV void emit_ray(const MqFrame& F, int round, uint32_t q, uint32_t slot, con
 // ---- first hit: gbuffer.comp:75-131 + start of mcpg.comp:39-57 --------------------------------
 template <bool GUIDED, bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSceneDev sc, MqParams P, MqFrame F) {
-    // one LDS region per wave, used first as traversal stack, then as lobe storage of the direction choice
-    __shared__ uint2 s_lds[MQ_WAVES][MQ_LDS_DWORDS2][64];
+    // one LDS region per wave, used first as traversal stack, then as lobe storage of the direction choice.
+    // (Tracing the primary rays in mq_trace_queue_kernel instead was measured: 0.36 ms there against
+    // 0.28 ms here -- a wave of this kernel is one 8x8 tile whose rays stay coherent to the end, while
+    // the dynamic fetch of the queue kernel mixes tiles -- plus one more launch per frame.)
+    extern __shared__ uint2 s_dyn[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2* stk = &s_lds[wave][0][lane];
-    float* lobes = GUIDED ? (float*)&s_lds[wave][0][0] + lane : nullptr;
+    uint2* stk = s_dyn + (size_t)wave * F.lds_rows2 * 64 + lane;
+    float* lobes = GUIDED ? (float*)(s_dyn + (size_t)wave * F.lds_rows2 * 64) + lane : nullptr;
     unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * MQ_BLOCK + threadIdx.x) * MQ_SPILL_ENTRIES;
     const uint32_t total = F.n_local_tiles * 64u;
     const mq_uniform& U = F.u;
@@ -841,10 +896,12 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
     Ctr ctr = {};
     const uint32_t stride = gridDim.x * MQ_BLOCK;
     const uint32_t rounds = (total + stride - 1) / stride;
+    PSTART(ctr);
     for (uint32_t it = 0; it < rounds; it++) {
         const uint32_t my = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
         bool cont = false;
         Path p = {};
+        PLAP(ctr, 0);
         if (my < total) {
             uint32_t ltile = my >> 6, within = my & 63u;
             uint32_t gtile = ltile * F.world + F.rank;
@@ -859,9 +916,11 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 f3 rd = camera_ray_dir((float)p.px, (float)p.py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
                 RayHit rhit;
                 traverse<COUNT>(sc, ro, rd, MQ_T_MAX, rhit, stk, spill, ctr);
+                PLAP(ctr, 1);
                 Hit h; h.pos = ro; h.wi = rd; h.prev_pos = ro; h.normal = F3(0, 0, 1); h.enc_geonormal = 0; h.albedo = F3(0, 0, 0); h.roughness = 0.0f;
                 f3 incident = F3(0, 0, 0), cthr = F3(1, 1, 1);
                 shade_hit(sc, P, U, rhit, cthr, incident, h, gb_sun);
+                PLAP(ctr, 2);
                 *(uint2*)(F.gb_irr + 4 * pidx) = make_uint2((uint32_t)f2h(incident.x) | ((uint32_t)f2h(incident.y) << 16), (uint32_t)f2h(incident.z) | (0x3c00u << 16));
                 float keep = (incident.x >= 1e-5f || incident.y >= 1e-5f || incident.z >= 1e-5f) ? 0.0f : 1.0f; // gbuffer.comp:107
                 h.albedo = rh3(rh3(h.albedo * keep) * cthr);
@@ -886,6 +945,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                     float vz = length(F3(U.prev_cam_x[0], U.prev_cam_x[1], U.prev_cam_x[2]) - h.prev_pos) - lz;
                     *(uint4*)(F.gbuffer + 4 * pidx) = make_uint4(encode_normal(h.normal), __float_as_uint(lz), g0 | (g1 << 16), __float_as_uint(vz));
                 }
+                PLAP(ctr, 3);
                 // mcpg.comp:44: pixels whose first hit carries no albedo get zero irradiance
                 if ((h.albedo.x >= 1e-7f || h.albedo.y >= 1e-7f || h.albedo.z >= 1e-7f) && P.spp > 0 && P.max_path_length > 1) {
                     load_chit(rec, p.cur); // the surface pass starts from the COMPRESSED first hit (mcpg.comp:46-47)
@@ -898,10 +958,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 }
             }
         }
+        PLAP(ctr, 9);
         uint32_t q = queue_append(F, 0, cont);
         if (cont) emit_ray(F, 0, q, my, p);
+        PLAP(ctr, 10);
     }
     if (COUNT) flush_counters(F.counters, ctr);
+    PFLUSH(F.counters, ctr);
 }
 
 // ---- closest hit for every queued ray ------------------------------------------------------------
@@ -909,7 +972,12 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 // wave's pool instead of idling until the longest traversal of the wave ends; pools are refilled
 // MQ_TRACE_BLOCKS blocks of its home shard at a time (one atomic on one of 16 per-shard heads), moving on
 // to the other shards when the home shard is drained, so no single word sees more than ~n/2048 atomics.
-#define MQ_TRACE_BLOCKS 4u // most 64-entry blocks fetched per refill (fewer for small queues, so that every resident wave gets rays)
+#ifndef MQ_TRACE_BLOCKS
+#define MQ_TRACE_BLOCKS 1u
+#endif
+// most 64-entry blocks fetched per refill.  One block: with 256-ray refills the ~7400 chunks of a 1080p
+// round spread over 6144 resident waves as "one or two each", i.e. a 2x makespan imbalance (measured:
+// 44 of 64 lanes busy on average, trace rounds 0.474 + 0.225 ms against 0.448 + 0.211 ms with 64-ray refills).
 #ifndef MQ_TRI_VOTE
 #define MQ_TRI_VOTE 16u
 #endif
@@ -924,23 +992,26 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     uint32_t* heads = F.ctrl + MQ_CTRL_HEAD0 + round * MQ_CTRL_GROUP;
     Ctr ctr = {};
     const uint32_t wave_id = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
+    const uint32_t n_eff = queue_view(tails).n_eff;
     if (sc.n_nodes == 0) { // empty scene: every ray misses
-        const QView qv = queue_view(tails);
-        for (uint32_t q = gid; q < qv.n_eff; q += gridDim.x * MQ_BLOCK) F.ray_hits[q] = make_uint4(MQ_NIL, 0x7f800000u, 0u, 0u);
+        const uint32_t lim = n_eff < F.ray_cap ? n_eff : F.ray_cap;
+        for (uint32_t q = gid; q < lim; q += gridDim.x * MQ_BLOCK) F.ray_hits[q] = make_uint4(MQ_NIL, 0x7f800000u, 0u, 0u);
         return;
     }
     // The wave's pool: `pool_len` entries of shard `pool_s`, starting at entry 64 * pool_j of that shard
     // (a run of MQ_TRACE_BLOCKS 64-entry blocks); `pool_i` entries are already handed out.  All wave-uniform.
     uint32_t pool_s = wave_id & (MQ_SHARDS - 1), pool_j = 0, pool_i = 0, pool_len = 0;
-    const uint32_t per_wave = queue_view(tails).n_eff / (gridDim.x * MQ_WAVES);
-    const uint32_t nblk = per_wave >= 64u * MQ_TRACE_BLOCKS ? MQ_TRACE_BLOCKS : (per_wave >= 128u ? 2u : 1u);
+    const uint32_t per_wave = n_eff / (gridDim.x * MQ_WAVES);
+    const uint32_t nblk = per_wave >= 64u * MQ_TRACE_BLOCKS ? MQ_TRACE_BLOCKS : (per_wave >= 128u && MQ_TRACE_BLOCKS >= 2u ? 2u : 1u);
     bool exhausted = false;
     bool busy = false;
     uint32_t q = 0;
     Trav t;
     trav_init(t, F3(0, 0, 0), F3(0, 0, 1), 0.0f);
+    PSTART(ctr);
     for (;;) {
         unsigned long long idle = __ballot(!busy);
+        PLAP(ctr, 24);
         if (idle) {
             while (pool_i == pool_len && !exhausted) { // refill: next run of blocks of the current shard
                 uint32_t cnt = 0, head = 0;
@@ -970,6 +1041,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
                     }
                 }
             }
+            PLAP(ctr, 25);
             const uint32_t avail = pool_len - pool_i;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!busy && rank < avail) {
@@ -983,10 +1055,15 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             pool_i += n_idle < avail ? n_idle : avail;
         }
+        PLAP(ctr, 26);
         if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
         // node phase: lanes without pending triangles visit one node
         const bool want_node = busy && t.tmask == 0;
+#ifdef MQ_PROF
+        { const uint32_t nn = (uint32_t)__popcll(__ballot(want_node)); if (nn) { ctr.prof[12]++; ctr.prof[13] += nn; } ctr.prof[11]++; ctr.prof[30] += (uint32_t)__popcll(__ballot(busy)); }
+#endif
         if (want_node) trav_node<COUNT>(sc, t, stk, spill, ctr);
+        PLAP(ctr, 27);
         // triangle phase, by wave vote: run it only when enough lanes have triangles pending (or no
         // lane could use another node phase), so the expensive test executes at useful occupancy
         const bool has_tri = busy && t.tmask != 0;
@@ -994,15 +1071,21 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
         const uint32_t ntri = (uint32_t)__popcll(tv);
         const uint32_t nbusy = (uint32_t)__popcll(__ballot(busy));
         if (ntri >= MQ_TRI_VOTE || ntri == nbusy) {
+#ifdef MQ_PROF
+            if (ntri) { ctr.prof[14]++; ctr.prof[15] += ntri; }
+#endif
             if (has_tri) trav_tri<COUNT>(sc, t, ctr);
         }
+        PLAP(ctr, 28);
         if (busy && t.tmask == 0) {
             if (trav_next(t, stk, spill)) {
                 F.ray_hits[q] = make_uint4(t.hit.tri, __float_as_uint(t.hit.t), __float_as_uint(t.hit.u), __float_as_uint(t.hit.v));
                 busy = false;
             }
         }
+        PLAP(ctr, 29);
     }
+    PFLUSH(F.counters, ctr);
     if (COUNT) { // counted separately so the trace kernel's own algorithmic bytes can be priced
         flush_counters(F.counters, ctr);
         uint32_t v[3] = {ctr.rays, ctr.nodes, ctr.tris};
@@ -1017,8 +1100,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
 // ---- a bounce ray returned: mcpg.comp:141-189, then the next direction ---------------------------
 template <bool GUIDED, bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSceneDev sc, MqParams P, MqFrame F, int round) {
-    __shared__ float s_lobes[GUIDED ? MQ_WAVES : 1][GUIDED ? 6 * MQ_MAX_MC_SAMPLES : 1][64];
-    float* lobes = GUIDED ? &s_lobes[threadIdx.x >> 6][0][threadIdx.x & 63] : nullptr;
+    extern __shared__ uint2 s_dyn[];
+    float* lobes = GUIDED ? (float*)(s_dyn + (size_t)(threadIdx.x >> 6) * F.lds_rows2 * 64) + (threadIdx.x & 63) : nullptr;
     const mq_uniform& U = F.u;
     const QView qv = queue_view(F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
     const uint32_t n = qv.n_eff;
@@ -1026,11 +1109,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
     Ctr ctr = {};
     const uint32_t stride = gridDim.x * MQ_BLOCK;
     const uint32_t iters = (n + stride - 1) / stride;
+    PSTART(ctr);
     for (uint32_t it = 0; it < iters; it++) {
         const uint32_t q = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
         bool cont = false;
         uint32_t slot = 0;
         Path p = {};
+        PLAP(ctr, 16);
         const bool valid = queue_valid(qv, q < n ? q : 0u);
         if (q < n && valid) {
             slot = F.queue_slots[round & 1][q];
@@ -1039,10 +1124,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
             Hit next; next.wi = p.wo; next.pos = p.cur.pos - p.cur.wi * 1e-3f; next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
             f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
+            PLAP(ctr, 17);
             shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
+            PLAP(ctr, 18);
             f3 lc_incident; // mcpg.comp:149
             if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
             else { lc_incident = rh3(throughput * light_cache_get(P, U, F.lc, p.rng, next.pos, next.normal)); if (COUNT) ctr.lc++; }
+            PLAP(ctr, 19);
             p.thr = p.thr * p.bsdf;
             if (P.use_light_cache_tail) p.fval = p.thr * (p.seg < P.max_path_length - 1 ? incident : lc_incident);
             else p.fval = p.thr * incident;
@@ -1054,6 +1142,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
                     float den = P.quirk_lc_max_wo_p ? mmax(p.wo_p, 10.0f) : mmax(p.wo_p, 1e-6f);
                     light_cache_update(P, U, F.lc, p.rng, p.cur.pos, p.cur.normal, ((lc_incident * (p.cur.albedo * MQ_INV_PI)) * p.wodotn) * (1.0f / den), ctr);
                     if (COUNT) ctr.lc++;
+                    PLAP(ctr, 20);
                     if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
                         f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
                         enqueue_update(P, F, p.rng, p.mc_index, p.mc_id, p.cur.pos, mc_f, next.pos, mv, p.cur.normal, ctr);
@@ -1062,6 +1151,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
                     }
                 }
             }
+            PLAP(ctr, 21);
             p.thr = p.thr * next.albedo; // :184
             p.cur = next;
             bool need_dir = false, sample_done = false;
@@ -1069,10 +1159,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             else { p.seg++; if (p.seg < P.max_path_length) need_dir = true; else sample_done = true; }
             cont = advance_path<GUIDED, COUNT>(P, F, p, slot, need_dir, sample_done, lobes, ctr);
         }
+        PLAP(ctr, 9);
         uint32_t qn = queue_append(F, round + 1, cont);
         if (cont) emit_ray(F, round + 1, qn, slot, p);
+        PLAP(ctr, 10);
     }
     if (COUNT) flush_counters(F.counters, ctr);
+    PFLUSH(F.counters, ctr);
 }
 
 
@@ -1386,6 +1479,7 @@ __global__ __launch_bounds__(256) void mq_link_kernel(MqFrame F) {
         const bool valid = queue_valid(qv, i < n ? i : 0u);
         if (!(i < n && valid)) continue;
         uint32_t* e3 = (uint32_t*)(F.queue + i) + 12;
+        if (e3[2] == MQ_NIL) continue; // an update dropped by the per-slot cap
         uint32_t prev = atomicExch(&F.upd_head[e3[2]], i + 1u);
         e3[3] = prev;
     }
@@ -1406,6 +1500,7 @@ __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
         const uint4* e = (const uint4*)(F.queue + i);
         uint4 e3 = e[3];
         uint32_t slot = e3.z;
+        if (slot == MQ_NIL) continue; // dropped by the cap at enqueue (counted there)
         if (*(volatile uint32_t*)&F.upd_head[slot] != i + 1u) continue;
         // chain length, then skip the newest arrivals beyond the cap
         uint32_t len = 0, at = i + 1u;
@@ -1533,9 +1628,12 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage; used by mq_api.cpp)
 // ------------------------------------------------------------------------------------------------
+// dynamic LDS bytes of a shading block: F.lds_rows2 rows of 64 x 8 bytes per wave
+static size_t shade_lds(const MqFrame& F) { return (size_t)F.lds_rows2 * 64 * 8 * MQ_WAVES; }
 int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s) {
-    if (guided) { if (count) mq_primary_kernel<true, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_primary_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
-    else { if (count) mq_primary_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); else mq_primary_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F); }
+    const size_t lds = shade_lds(F);
+    if (guided) { if (count) mq_primary_kernel<true, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); else mq_primary_kernel<true, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); }
+    else { if (count) mq_primary_kernel<false, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); else mq_primary_kernel<false, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); }
     return (int)hipGetLastError();
 }
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s) {
@@ -1543,8 +1641,9 @@ int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, boo
     return (int)hipGetLastError();
 }
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s) {
-    if (guided) { if (count) mq_bounce_kernel<true, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); else mq_bounce_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); }
-    else { if (count) mq_bounce_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); else mq_bounce_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, round); }
+    const size_t lds = guided ? shade_lds(F) : 0;
+    if (guided) { if (count) mq_bounce_kernel<true, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); else mq_bounce_kernel<true, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); }
+    else { if (count) mq_bounce_kernel<false, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); else mq_bounce_kernel<false, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); }
     return (int)hipGetLastError();
 }
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
@@ -1586,3 +1685,19 @@ int mq_launch_volume_finish(const MqParams& P, const MqFrame& F, int grid, hipSt
 }
 int mq_render_block_size() { return MQ_BLOCK; }
 int mq_spill_entries() { return MQ_SPILL_ENTRIES; }
+int mq_stack_lds_entries() { return MQ_STACK_LDS; }
+// resident blocks per CU of the three frame kernels at the given dynamic LDS size: {primary, trace, bounce}
+int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int out[3]) {
+    int a = 0, b = 0, c = 0;
+    hipError_t e;
+    if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<true, false>, MQ_BLOCK, shade_lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<false, false>, MQ_BLOCK, shade_lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false>, MQ_BLOCK, 0);
+    if (e != hipSuccess) return (int)e;
+    if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<true, false>, MQ_BLOCK, shade_lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<false, false>, MQ_BLOCK, 0);
+    if (e != hipSuccess) return (int)e;
+    out[0] = a; out[1] = b; out[2] = c;
+    return 0;
+}

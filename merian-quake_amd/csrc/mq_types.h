@@ -63,6 +63,20 @@ struct MqTexDesc {
     uint32_t flags;
 };
 
+// 64-byte shading record per triangle, in BVH triangle order (same index as MqTri): the triangle's
+// 28-byte extra data (scene_info.glsl.h:7-16) with the descriptors of its albedo and fullbright
+// textures resolved at commit time, so that a hit needs ONE dependent fetch (triangle + record, issued
+// together) before the texel reads instead of triangle -> extra data -> descriptor -> texels.
+struct MqShadeRec {
+    uint32_t ext[7];
+    uint32_t pad0;
+    MqTexDesc albedo; // tex[min(texnum, MQ_MAX_GLTEXTURES - 1)]
+    uint32_t pad1;
+    MqTexDesc fb;     // tex[fullbright texnum] (valid when the texnum is in range; raytrace.glsl:296)
+    uint32_t pad2;
+};
+static_assert(sizeof(MqShadeRec) == 64, "shade record must be 64 bytes");
+
 // 64-byte Markov-chain state (reference MCState is 52 B scalar, grid.h:6-21; the three
 // *_change debug fields are never written by this fork and are dropped).
 struct MqMCState {
@@ -143,6 +157,7 @@ struct MqGeoDev {
 struct MqSceneDev {
     const MqNode* nodes;
     const MqTri* tris;
+    const MqShadeRec* shade; // one per triangle, same order as tris
     MqGeoDev geo[MQ_MAX_GEOMETRIES];
     const MqTexDesc* tex;
     const uint32_t* texels;
@@ -153,9 +168,11 @@ struct MqSceneDev {
 // 16-byte distance Markov-chain state, grid.h:48-52
 struct MqDistMC { float sum_w; uint32_t N; float m0, m1; };
 
+#define MQ_PROF_SECTIONS 32
 struct MqCountersDev {
     unsigned long long rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels, lc_ok, lc_cancel, q_rays, q_nodes, q_tris, q_paths;
+    unsigned long long prof[MQ_PROF_SECTIONS]; // -DMQ_PROF builds: shader clocks per code section, summed over waves
 };
 
 // Per-frame launch block of the render kernel.
@@ -199,4 +216,6 @@ struct MqFrame {
     uint32_t count_stats;  // != 0: kernels without a COUNT instantiation may bump `counters` too
     // traversal stack spill area: MQ_SPILL_ENTRIES 8-byte entries per resident lane
     unsigned long long* stack_spill;
+    // dynamic LDS of the shading kernels: 8-byte rows of 64 lanes per wave (lobe storage: 3 rows per Markov-chain sample)
+    uint32_t lds_rows2;
 };

@@ -112,9 +112,11 @@ def load_library(path=None):
         "mq_timing_reset": (i32, [P]),
         "mq_timing_get": (i32, [P, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mq_timing_get_detail": (i32, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "mq_timing_get_rounds": (i32, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
         "mq_enable_counters": (i32, [P, i32]),
         "mq_get_counters": (i32, [P, C.POINTER(Counters)]),
         "mq_reset_state": (i32, [P]),
+        "mq_debug_section_clocks": (i32, [P, C.POINTER(C.c_uint64), i32, i32]),
         "mq_set_partition": (i32, [P, i32, i32]),
         "mq_tiles_per_rank": (i32, [P, u32p, C.POINTER(sz)]),
         "mq_untile": (i32, [P, vp, vp]),
@@ -308,6 +310,12 @@ class Context:
         self._chk(self.lib.mq_timing_get_detail(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(primary_ms=a.value, trace_ms=b.value, bounce_ms=c.value)
 
+    def timing_rounds(self):
+        """[(trace_ms_sum, shade_ms_sum)]: entry 0 = primary rays / first-hit shading, entry 1 + r = round r."""
+        a, b = (C.c_double * 9)(), (C.c_double * 9)()
+        self._chk(self.lib.mq_timing_get_rounds(self.h, a, b, 9))
+        return list(zip(a, b))
+
     def enable_counters(self, on):
         self._chk(self.lib.mq_enable_counters(self.h, 1 if on else 0))
 
@@ -315,6 +323,12 @@ class Context:
         c = Counters()
         self._chk(self.lib.mq_get_counters(self.h, C.byref(c)))
         return c.as_dict()
+
+    def section_clocks(self, reset=True):
+        """-DMQ_PROF builds: shader clocks per code section (tools/prof_sections.py); zeros otherwise."""
+        a = (C.c_uint64 * 32)()
+        self._chk(self.lib.mq_debug_section_clocks(self.h, a, 32, 1 if reset else 0))
+        return list(a)
 
     def reset_state(self):
         self._chk(self.lib.mq_reset_state(self.h))

@@ -268,7 +268,9 @@ def test_volume_guiding_is_unbiased(gpu_ctx):
     """Guided distance + direction sampling (Markov chains on) converges to the same mean in-scattered
     radiance as pure transmittance / phase sampling (MIS keeps it unbiased, volume.comp:96-103,168-175)."""
     ctx = gpu_ctx
-    W, H, N = 64, 48, 160
+    # the guided estimator is heavy tailed: at 64x48x160 the relative difference has sigma ~6 % (measured
+    # over 8 runs, mean -2 %), so the test averages 6x as many samples for a 10 % (~4 sigma) bound
+    W, H, N = 128, 96, 240
     means = {}
     for guided in (0, 1):
         props = {"reference mode": 0, "spp": 1, **VOL}

@@ -1,0 +1,54 @@
+"""Section report of a -DMQ_PROF build (in-kernel lap profiling, see PLAP in csrc/mq_kernels.hip).
+
+    make -C merian-quake_amd EXTRA=-DMQ_PROF B=build/prof OUT=lib/libmqhip_prof.so
+    MQHIP_LIB=merian-quake_amd/lib/libmqhip_prof.so python tools/prof_sections.py [--width W --height H]
+
+Prints the share of wave-clocks each code section of the frame kernels takes (clocks between laps
+of a wave include the time its SIMD spent on other waves, so read the numbers as shares)."""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
+import mqhip
+
+SECTIONS = {
+    0: "primary: loop overhead", 1: "primary: traversal", 2: "primary: shade first hit", 3: "primary: g-buffer stores",
+    4: "advance: entry", 5: "advance: K state lookups", 6: "advance: sample direction", 7: "advance: pdf mixture",
+    8: "advance: bsdf value", 9: "advance: sample/pixel finish", 10: "append + emit ray/path",
+    16: "bounce: loop overhead", 17: "bounce: load path + hit", 18: "bounce: shade hit", 19: "bounce: light cache get",
+    20: "bounce: light cache update", 21: "bounce: enqueue update",
+    24: "trace: ballot", 25: "trace: refill", 26: "trace: ray fetch", 27: "trace: node phase", 28: "trace: triangle phase", 29: "trace: pop/writeback",
+}
+GROUPS = {"primary": [0, 1, 2, 3], "shared by primary+bounce": [4, 5, 6, 7, 8, 9, 10], "bounce": [16, 17, 18, 19, 20, 21], "trace": [24, 25, 26, 27, 28, 29]}
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="synth_sepulcher"); ap.add_argument("--frames", type=int, default=20)
+    a = ap.parse_args()
+    ctx = mqhip.Context(0)
+    ctx.json_defaults()
+    for k, v in {"randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3, "reference mode": 0, "volume spp": 0}.items():
+        ctx.set_property(k, v)
+    ctx.synth_scene(a.scene, 2); ctx.commit(); ctx.connect(a.width, a.height)
+    for f in range(10):
+        ctx.process(ctx.synth_camera(f))
+    ctx.section_clocks(reset=True)
+    for f in range(10, 10 + a.frames):
+        ctx.process(ctx.synth_camera(f))
+    clk = ctx.section_clocks()
+    # lane utilisation counters of the trace loop (not clocks)
+    it, nb, n_exec, n_lanes, t_exec, t_lanes = clk[11], clk[30], clk[12], clk[13], clk[14], clk[15]
+    for i in (11, 12, 13, 14, 15, 30):
+        clk[i] = 0
+    if it:
+        print(f"trace loop: {it} iterations, busy lanes {nb / it:.1f}/64; node phase ran in {100 * n_exec / it:.0f} % with {n_lanes / max(n_exec, 1):.1f} lanes; "
+              f"triangle phase ran in {100 * t_exec / it:.0f} % with {t_lanes / max(t_exec, 1):.1f} lanes")
+    tot = float(sum(clk)) or 1.0
+    for g, ids in GROUPS.items():
+        gs = sum(clk[i] for i in ids)
+        print(f"{g}: {100 * gs / tot:.1f} % of all wave-clocks")
+        for i in ids:
+            print(f"   {SECTIONS[i]:34s} {100 * clk[i] / tot:6.2f} %   ({100 * clk[i] / max(gs, 1):5.1f} % of group)")
+
+if __name__ == "__main__":
+    main()
