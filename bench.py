@@ -17,6 +17,7 @@ per launch (counted by an instrumented launch of the same kernel on the same fra
 divided by its average launch duration measured with HIP events on the launch stream.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -28,6 +29,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def pmc_traffic(kernel, default_workload):
+    """HBM bytes per launch of `kernel` from the newest committed counter summary (profiles/*_pmc_summary.json,
+    written by tools/profile_round.sh + tools/collect_profiles.py from separate rocprofv3 --pmc passes over this
+    same command: 1024 * (2 * FETCH_SIZE + WRITE_SIZE), the gfx950 correction of MI355X_MICROARCH.md).  Counters
+    cannot be read from inside the process, so the figure is only reported for the default workload they were
+    collected on; None otherwise."""
+    if not default_workload:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))  # named per round: the last name is the newest
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for name, v in d.items():
+            if name.startswith(kernel) and "true>" not in name.split(",")[-1] and "hbm_bytes_per_launch" in v:
+                return int(v["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def algorithmic_bytes(c, pixels):
@@ -192,8 +213,11 @@ def main():
     dom_bytes_per_launch = kbytes[dom] / launches[dom]
     achieved = dom_bytes_per_launch / (dom_ms_per_launch * 1e-3) / 1e9
     pipeline_ms = render_sum / n_timed
+    default_workload = (world == 1 and (W, H) == (1920, 1080) and args.scene == "synth_sepulcher" and args.scene_seed == 2
+                        and args.spp == 1 and not args.reference_mode and args.volume_spp == 0)
+    traffic, traffic_src = pmc_traffic(dom, default_workload)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dom,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                 "kernel_ms_per_launch": round(dom_ms_per_launch, 4), "launches_per_frame": launches[dom],
                 "algorithmic_bytes_per_launch": int(dom_bytes_per_launch),
                 "frame": {"algorithmic_bytes": int(B), "render_ms": round(pipeline_ms, 4), "achieved": round(B / (pipeline_ms * 1e-3) / 1e9, 1),

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Profiles of the default bench workload for profiles/ (run on the GPU box through gpurun):
+#   tools/profile_round.sh <tag>          e.g.  gpurun -- 'tools/profile_round.sh r01_final'
+# 1. rocprofv3 --kernel-trace --stats of `python3 bench.py` (same command the bench numbers come from)
+# 2. counter passes (separate runs, counters only): FETCH_SIZE ; WRITE_SIZE + TCC hit/miss
+# Everything lands in gpurun_out/<tag>/ ; tools/collect_profiles.py copies the summaries to profiles/.
+set -e
+tag=${1:-r01}
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+args="--steps 50 --warmup 20 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o run --output-format csv -- python3 $root/bench.py $args > $out/bench_under_rocprof.json 2> $out/trace.log
+echo "kernel trace done"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o run --output-format csv -- python3 $root/bench.py $args > /dev/null 2> $out/pmc_fetch.log
+echo "FETCH_SIZE pass done"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $out/pmc_write -o run --output-format csv -- python3 $root/bench.py $args > /dev/null 2> $out/pmc_write.log
+echo "WRITE_SIZE pass done"
+timeout -k 10 300 python3 $root/bench.py --steps 50 --warmup 20 > $out/bench.json 2> $out/bench.log
+echo "plain bench done"
