@@ -188,7 +188,8 @@ int mq_enable_counters(mq_ctx* ctx, int on);
 int mq_get_counters(mq_ctx* ctx, mq_counters* out);
 int mq_reset_state(mq_ctx* ctx); /* next process() behaves like iteration 0 */
 /* Profiling builds (-DMQ_PROF) only: shader clocks per kernel code section, summed over all waves
- * since the last reset; all zero in a product build.  Section ids: tools/prof_sections.py. */
+ * since the last reset, followed by 64 histogram bins (rays by loop iterations in the queue kernel, bins of 8);
+ * all zero in a product build.  Section ids: tools/prof_sections.py. */
 #define MQ_PROF_SECTION_COUNT 32
 int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 

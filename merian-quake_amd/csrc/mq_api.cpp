@@ -57,7 +57,7 @@ struct mq_ctx {
     float sah_cost = 0.0f;
     bool committed = false;
     // device scene
-    DevBuf d_nodes, d_tris, d_shade, d_texdesc, d_texels, d_lut;
+    DevBuf d_nodes, d_tris, d_shade, d_texdesc, d_texels;
     DevBuf d_ext[MQ_MAX_GEOMETRIES], d_idx[MQ_MAX_GEOMETRIES], d_prev[MQ_MAX_GEOMETRIES];
     MqSceneDev scene{};
     // frame state
@@ -117,6 +117,10 @@ int dev_alloc(mq_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     HIPCHK(c, hipMalloc(&b.p, bytes));
     b.bytes = bytes;
+    // hipMalloc does not initialise: with MQ_DEBUG_POISON set every fresh buffer is filled with 0xff bytes
+    // (NaN floats, MQ_NIL indices), so a read of memory nobody wrote shows up instead of "working by luck"
+    static const bool poison = getenv("MQ_DEBUG_POISON") != nullptr;
+    if (poison) HIPCHK(c, hipMemset(b.p, 0xff, bytes));
     return MQ_OK;
 }
 int dev_upload(mq_ctx* c, DevBuf& b, const void* src, size_t bytes) {
@@ -293,7 +297,7 @@ void free_frame_state(mq_ctx* c) {
     c->connected = false;
 }
 void free_scene_dev(mq_ctx* c) {
-    dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels); dev_free(c->d_lut);
+    dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels);
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
 }
 
@@ -560,12 +564,25 @@ int mq_scene_commit(mq_ctx* c) {
         }
         if ((r = dev_upload(c, c->d_shade, recs.data(), recs.size() * sizeof(MqShadeRec)))) return r;
     }
-    if ((r = dev_upload(c, c->d_texels, pool.data(), pool.size() * 4))) return r;
-    float lut[256];
-    for (int i = 0; i < 256; i++) { double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4)); }
-    if ((r = dev_upload(c, c->d_lut, lut, sizeof lut))) return r;
+    { // decode the pool once: sRGB through the 256-entry table (quake_node.hpp:93-95), everything else x / 255
+        float lut[256];
+        for (int i = 0; i < 256; i++) { double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4)); }
+        std::vector<float> lin(pool.size() * 4);
+        for (uint32_t t = 0; t < MQ_MAX_GLTEXTURES; t++) {
+            if (desc[t].offset == MQ_NIL) continue;
+            const bool srgb = (desc[t].flags & MQ_TEX_SRGB) != 0;
+            const size_t n = (size_t)desc[t].w * desc[t].h;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t p = pool[desc[t].offset + i];
+                float* o = &lin[4 * (desc[t].offset + i)];
+                for (int k = 0; k < 3; k++) { const uint32_t b = (p >> (8 * k)) & 0xffu; o[k] = srgb ? lut[b] : (float)b * (1.0f / 255.0f); }
+                o[3] = (float)(p >> 24) * (1.0f / 255.0f);
+            }
+        }
+        if ((r = dev_upload(c, c->d_texels, lin.data(), lin.size() * 4))) return r;
+    }
     c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p; c->scene.shade = (const MqShadeRec*)c->d_shade.p;
-    c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const uint32_t*)c->d_texels.p; c->scene.srgb_lut = (const float*)c->d_lut.p;
+    c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const float4*)c->d_texels.p;
     c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
     return MQ_OK;
 }
@@ -672,7 +689,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
     F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.counters = (MqCountersDev*)c->d_counters.p; F.count_stats = c->count_enabled ? 1u : 0u;
     F.stack_spill = (unsigned long long*)c->d_spill.p;
-    F.paths = (uint4*)c->d_paths.p; F.rays = (float4*)c->d_rays.p; F.ray_hits = (uint4*)c->d_ray_hits.p;
+    F.paths = (uint4*)c->d_paths.p; F.n_slots = c->tiles_per_rank * 64u; F.rays = (float4*)c->d_rays.p; F.ray_hits = (uint4*)c->d_ray_hits.p;
     F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p; F.ray_cap = c->ray_cap;
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
     F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
@@ -875,8 +892,8 @@ int mq_debug_section_clocks(mq_ctx* c, uint64_t* out, int n, int reset) {
     HIPCHK(c, hipStreamSynchronize(c->last_stream));
     MqCountersDev d;
     HIPCHK(c, hipMemcpy(&d, c->d_counters.p, sizeof d, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n && i < MQ_PROF_SECTIONS; i++) out[i] = d.prof[i];
-    if (reset) HIPCHK(c, hipMemset((char*)c->d_counters.p + offsetof(MqCountersDev, prof), 0, sizeof d.prof));
+    for (int i = 0; i < n && i < MQ_PROF_SECTIONS + 64; i++) out[i] = i < MQ_PROF_SECTIONS ? d.prof[i] : d.ray_hist[i - MQ_PROF_SECTIONS];
+    if (reset) HIPCHK(c, hipMemset((char*)c->d_counters.p + offsetof(MqCountersDev, prof), 0, sizeof d.prof + sizeof d.ray_hist));
     return MQ_OK;
 }
 
@@ -915,9 +932,9 @@ int mq_trace_rays(mq_ctx* c, const float* org, const float* dir, uint32_t n, uin
     return r;
 }
 
-static const int k_arity[16][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}};
+static const int k_arity[18][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}, {3, 4}, {7, 3}};
 int mq_math_eval(mq_ctx* c, int op, const float* in, float* out, uint32_t n) {
-    if (!c || !in || !out || op < 0 || op >= 16) return MQ_EINVAL;
+    if (!c || !in || !out || op < 0 || op >= 18) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
     if (n == 0) return MQ_OK;
     HIPCHK(c, hipSetDevice(c->device));

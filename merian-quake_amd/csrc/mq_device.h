@@ -112,9 +112,15 @@ MQ_DEV float mq_sin(float x) {
 }
 
 // ---- half precision: round-to-nearest-even hardware conversions -----------------------------
-MQ_DEV uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(f)); }
+// float -> half, round to nearest even, of a value that HAS BEEN ROUNDED TO FLOAT FIRST.  Without the
+// (empty) asm the instruction selector folds the conversion into the producing multiply / add
+// (v_fma_mixlo_f16: one rounding straight to half), which differs from round-to-float-then-to-half --
+// what the oracle and any IEEE two-step evaluation give -- whenever the float result sits next to a
+// half-precision tie.  One such fold per kernel made a pixel differ in one channel by one half ulp.
+MQ_DEV float rounded_f32(float f) { asm("" : "+v"(f)); return f; }
+MQ_DEV uint16_t f2h(float f) { return __half_as_ushort(__float2half_rn(rounded_f32(f))); }
 MQ_DEV float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-MQ_DEV float rh(float f) { return __half2float(__float2half_rn(f)); }
+MQ_DEV float rh(float f) { return __half2float(__float2half_rn(rounded_f32(f))); }
 MQ_DEV f3 rh3(f3 a) { return F3(rh(a.x), rh(a.y), rh(a.z)); }
 MQ_DEV bool h_bad(uint16_t h) { return (h & 0x7c00u) == 0x7c00u; }
 

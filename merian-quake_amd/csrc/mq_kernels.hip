@@ -68,17 +68,16 @@ MQ_DEV void prof_flush(MqCountersDev* g, const Ctr& c) {
 #endif
 
 // ------------------------------------------------------------------------------------------------
-// textures: RGBA8 texel pool, REPEAT wrap, nearest or bilinear, sRGB decode through a LUT
+// textures: texel pool decoded to linear RGBA32F at commit (sRGB LUT or x/255, the values a per-fetch decode
+// would give), REPEAT wrap, nearest or bilinear: a texel is ONE 16-byte gather instead of a packed texel plus
+// three LUT gathers
 // ------------------------------------------------------------------------------------------------
 struct f4 { float r, g, b, a; };
 
 // REPEAT addressing without integer division: u = s - floor(s) in [0,1], then scale by the size
 MQ_DEV f4 texel(const MqSceneDev& sc, const MqTexDesc& t, int x, int y) { // x, y already in range
-    uint32_t p = sc.texels[t.offset + (uint32_t)y * t.w + (uint32_t)x];
-    f4 r;
-    if (t.flags & MQ_TEX_SRGB) { r.r = sc.srgb_lut[p & 0xff]; r.g = sc.srgb_lut[(p >> 8) & 0xff]; r.b = sc.srgb_lut[(p >> 16) & 0xff]; }
-    else { r.r = (float)(p & 0xff) * (1.0f / 255.0f); r.g = (float)((p >> 8) & 0xff) * (1.0f / 255.0f); r.b = (float)((p >> 16) & 0xff) * (1.0f / 255.0f); }
-    r.a = (float)(p >> 24) * (1.0f / 255.0f);
+    const float4 p = sc.texels[t.offset + (uint32_t)y * t.w + (uint32_t)x];
+    f4 r; r.r = p.x; r.g = p.y; r.b = p.z; r.a = p.w;
     return r;
 }
 MQ_DEV int tex_nearest_coord(float s, float fw, int w) {
@@ -120,7 +119,7 @@ MQ_DEV float tex_gather_alpha_r(const MqSceneDev& sc, const MqTexDesc& tx, float
     int x0, x1, y0, y1; float fx, fy;
     tex_linear_coord(s, (float)tx.w, (int)tx.w, x0, x1, fx);
     tex_linear_coord(t, (float)tx.h, (int)tx.h, y0, y1, fy);
-    return texel(sc, tx, x0, y1).a;
+    return ((const float*)(sc.texels + (tx.offset + (uint32_t)y1 * tx.w + (uint32_t)x0)))[3]; // alpha only: 4 bytes
 }
 
 
@@ -208,8 +207,9 @@ MQ_DEV uint32_t box4(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_
 // and the persistent queue kernel interleaves steps of different rays in one wave.
 struct Trav {
     f3 o, d;
-    float idx, idy, idz, tmax;
-    uint32_t octinv; // bit k set: direction component k is >= 0
+    float idx, idy, idz;
+    float tlim;      // box-test limit: min(closest hit, MQ_T_MAX) * (1 + 2^-20) + 1e-6, refreshed when a hit is accepted
+    uint32_t oct4;   // octinv in every byte; octinv bit k set: direction component k is >= 0
     uint2 G;
     int sp;
     RayHit hit;
@@ -217,12 +217,13 @@ struct Trav {
     uint32_t tmask, tbase; // triangles of the last visited node that still have to be tested
 };
 
-MQ_DEV void trav_init(Trav& t, f3 o, f3 d, float tmax) {
-    t.o = o; t.d = d; t.tmax = tmax;
+MQ_DEV float trav_limit(float t_closest) { return t_closest * 1.000001f + 1e-6f; }
+MQ_DEV void trav_init(Trav& t, f3 o, f3 d) { // rays end at MQ_T_MAX (raytrace.glsl:82-119)
+    t.o = o; t.d = d; t.tlim = trav_limit(MQ_T_MAX);
     t.idx = 1.0f / (fabsf(d.x) > 1e-20f ? d.x : (d.x < 0.0f ? -1e-20f : 1e-20f));
     t.idy = 1.0f / (fabsf(d.y) > 1e-20f ? d.y : (d.y < 0.0f ? -1e-20f : 1e-20f));
     t.idz = 1.0f / (fabsf(d.z) > 1e-20f ? d.z : (d.z < 0.0f ? -1e-20f : 1e-20f));
-    t.octinv = (d.x < 0.0f ? 0u : 1u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 4u);
+    t.oct4 = ((d.x < 0.0f ? 0u : 1u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 4u)) * 0x01010101u;
     t.G = make_uint2(0u, 0x80000000u);
     t.sp = 0;
     t.hit.tri = MQ_NIL; t.hit.t = __uint_as_float(0x7f800000u); t.hit.u = 0.0f; t.hit.v = 0.0f;
@@ -234,7 +235,7 @@ MQ_DEV void trav_init(Trav& t, f3 o, f3 d, float tmax) {
 // leaves that were hit are left in t.tmask / t.tbase.  Precondition: t.G has a pending child.
 template <bool COUNT>
 MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane] */, unsigned long long* spill, Ctr& ctr) {
-    const bool sx = !(t.octinv & 1u), sy = !(t.octinv & 2u), sz = !(t.octinv & 4u);
+    const bool sx = !(t.oct4 & 1u), sy = !(t.oct4 & 2u), sz = !(t.oct4 & 4u);
     uint2 G = t.G;
     uint32_t bit = 31u - (uint32_t)__clz((int)G.y);
     G.y &= ~(1u << bit);
@@ -243,15 +244,17 @@ MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane]
         else spill[t.sp - MQ_STACK_LDS] = ((unsigned long long)G.y << 32) | G.x;
         t.sp++;
     }
-    uint32_t slot = (bit - 24u) ^ t.octinv;
+    uint32_t slot = (bit - 24u) ^ (t.oct4 & 7u);
     uint32_t rel = (uint32_t)__popc(G.y & 0xffu & ((1u << slot) - 1u));
     const uint4* np = (const uint4*)(sc.nodes + (G.x + rel));
     uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
     if (COUNT) ctr.nodes++;
-    float tlim = fminf(t.hit.t, t.tmax) * 1.000001f + 1e-6f;
-    float adx = __uint_as_float((n0.w & 0xffu) << 23) * t.idx;
-    float ady = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * t.idy;
-    float adz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * t.idz;
+    const float tlim = t.tlim;
+    // 1/d scaled by the node's power-of-two cell size: an exponent-field add (exact; |1/d| is in [1, 1e20] and the
+    // biased exponents are far from both ends of the range)
+    float adx = __uint_as_float(__float_as_uint(t.idx) + ((n0.w & 0xffu) << 23) - (127u << 23));
+    float ady = __uint_as_float(__float_as_uint(t.idy) + (((n0.w >> 8) & 0xffu) << 23) - (127u << 23));
+    float adz = __uint_as_float(__float_as_uint(t.idz) + (((n0.w >> 16) & 0xffu) << 23) - (127u << 23));
     float ox = (__uint_as_float(n0.x) - t.o.x) * t.idx;
     float oy = (__uint_as_float(n0.y) - t.o.y) * t.idy;
     float oz = (__uint_as_float(n0.z) - t.o.z) * t.idz;
@@ -259,11 +262,12 @@ MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane]
     uint32_t nx0 = sx ? n3.z : n2.x, nx1 = sx ? n3.w : n2.y, fx0 = sx ? n2.x : n3.z, fx1 = sx ? n2.y : n3.w;
     uint32_t ny0 = sy ? n4.x : n2.z, ny1 = sy ? n4.y : n2.w, fy0 = sy ? n2.z : n4.x, fy1 = sy ? n2.w : n4.y;
     uint32_t nz0 = sz ? n4.z : n3.x, nz1 = sz ? n4.w : n3.y, fz0 = sz ? n3.x : n4.z, fz1 = sz ? n3.y : n4.w;
-    uint32_t oct4 = t.octinv | (t.octinv << 8); oct4 |= oct4 << 16; // octinv in every byte
+    const uint32_t oct4 = t.oct4;
     uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, oct4) |
                   box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, oct4);
 #ifdef MQ_EXP_DUMMY_VALU // experiment: extra dependent VALU work per node visit (is the kernel issue bound?)
-    { float z = adx; for (int i = 0; i < MQ_EXP_DUMMY_VALU; i++) z = __builtin_fmaf(z, ady, adz); if (z == 123.456f) hm ^= 1u; }
+    { float z[8]; for (int k = 0; k < 8; k++) z[k] = adx + (float)k; for (int i = 0; i < MQ_EXP_DUMMY_VALU / 8; i++) for (int k = 0; k < 8; k++) z[k] = __builtin_fmaf(z[k], ady, adz); // 8 independent chains
+      float zs = 0.0f; for (int k = 0; k < 8; k++) zs += z[k]; if (zs == 123.456f) hm ^= 1u; }
 #endif
 #ifdef MQ_EXP_DUMMY_LOAD // experiment: extra 16-byte gathers per node visit (is the kernel L1 bound?)
     { uint32_t acc = 0; for (int i = 0; i < MQ_EXP_DUMMY_LOAD; i++) { uint4 x = ((const uint4*)(sc.nodes + ((G.x + rel + 977u * (i + 1)) % sc.n_nodes)))[i % 5]; acc ^= x.x; } if (acc == 0x12345678u) hm ^= 1u; }
@@ -290,9 +294,9 @@ MQ_DEV void trav_tri(const MqSceneDev& sc, Trav& t, Ctr& ctr) {
     bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
                             F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
                             F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), tt, u, v);
-    accept = accept && (tt < t.tmax) && (tt < t.hit.t || (tt == t.hit.t && c.y < t.best_key));
+    accept = accept && (tt < MQ_T_MAX) && (tt < t.hit.t || (tt == t.hit.t && c.y < t.best_key));
     if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, t.tbase + k, u, v);
-    if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = t.tbase + k; t.best_key = c.y; }
+    if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = t.tbase + k; t.best_key = c.y; t.tlim = trav_limit(tt); }
 }
 
 // After the pending triangles are done: continue with the current group or pop the stack.
@@ -301,8 +305,8 @@ MQ_DEV bool trav_next(Trav& t, uint2* stk, unsigned long long* spill) {
     if (t.G.y > 0x00ffffffu) return false;
     if (t.sp == 0) return true;
     t.sp--;
-    if (t.sp < MQ_STACK_LDS) t.G = stk[t.sp * 64];
-    else { unsigned long long e = spill[t.sp - MQ_STACK_LDS]; t.G = make_uint2((uint32_t)e, (uint32_t)(e >> 32)); }
+    t.G = stk[(t.sp < MQ_STACK_LDS ? t.sp : 0) * 64]; // the common case: one LDS read, no address select
+    if (t.sp >= MQ_STACK_LDS) { unsigned long long e = spill[t.sp - MQ_STACK_LDS]; t.G = make_uint2((uint32_t)e, (uint32_t)(e >> 32)); } // deep stacks only
     return false;
 }
 
@@ -315,9 +319,9 @@ MQ_DEV bool trav_step(const MqSceneDev& sc, Trav& t, uint2* stk, unsigned long l
 }
 
 template <bool COUNT>
-MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, float tmax, RayHit& hit, uint2* stk, unsigned long long* spill, Ctr& ctr) {
+MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, RayHit& hit, uint2* stk, unsigned long long* spill, Ctr& ctr) {
     Trav t;
-    trav_init(t, o, d, tmax);
+    trav_init(t, o, d);
     if (COUNT) ctr.rays++;
     if (sc.n_nodes != 0) while (!trav_step<COUNT>(sc, t, stk, spill, ctr)) {}
     hit = t.hit;
@@ -670,20 +674,22 @@ struct Path {
     bool lm_dir_ok;
 };
 
-MQ_DEV void store_path(uint4* dst, const Path& p) {
-    dst[0] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(p.cur.prev_pos.x));
-    dst[1] = make_uint4(__float_as_uint(p.cur.prev_pos.y), __float_as_uint(p.cur.prev_pos.z), __float_as_uint(p.cur.wi.x), __float_as_uint(p.cur.wi.y));
-    dst[2] = make_uint4(__float_as_uint(p.cur.wi.z), __float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z));
-    dst[3] = make_uint4(p.cur.enc_geonormal, (uint32_t)f2h(p.cur.albedo.x) | ((uint32_t)f2h(p.cur.albedo.y) << 16), (uint32_t)f2h(p.cur.albedo.z) | ((uint32_t)f2h(p.cur.roughness) << 16), p.rng);
-    dst[4] = make_uint4(__float_as_uint(p.thr.x), __float_as_uint(p.thr.y), __float_as_uint(p.thr.z), __float_as_uint(p.pp));
-    dst[5] = make_uint4(__float_as_uint(p.fval.x), __float_as_uint(p.fval.y), __float_as_uint(p.fval.z), __float_as_uint(p.m2));
-    dst[6] = make_uint4(__float_as_uint(p.irr.x), __float_as_uint(p.irr.y), __float_as_uint(p.irr.z), p.px | (p.py << 16));
-    dst[7] = make_uint4(__float_as_uint(p.wo.x), __float_as_uint(p.wo.y), __float_as_uint(p.wo.z), __float_as_uint(p.wo_p));
-    dst[8] = make_uint4(__float_as_uint(p.bsdf), __float_as_uint(p.wodotn), __float_as_uint(p.score_sum), __float_as_uint(p.mc_sum_w));
-    dst[9] = make_uint4(p.mc_index, p.mc_id, (uint32_t)p.seg | ((uint32_t)p.smp << 8) | (p.lm_dir_ok ? 0x10000u : 0u), 0u);
+// Path records are FIELD-MAJOR: 16-byte field k of slot s sits at paths[k * n_slots + s], so the loads and
+// stores of a wave (consecutive slots) are contiguous instead of 160 bytes apart.
+MQ_DEV void store_path(uint4* dst /* paths + slot */, size_t n, const Path& p) {
+    dst[0 * n] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(p.cur.prev_pos.x));
+    dst[1 * n] = make_uint4(__float_as_uint(p.cur.prev_pos.y), __float_as_uint(p.cur.prev_pos.z), __float_as_uint(p.cur.wi.x), __float_as_uint(p.cur.wi.y));
+    dst[2 * n] = make_uint4(__float_as_uint(p.cur.wi.z), __float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z));
+    dst[3 * n] = make_uint4(p.cur.enc_geonormal, (uint32_t)f2h(p.cur.albedo.x) | ((uint32_t)f2h(p.cur.albedo.y) << 16), (uint32_t)f2h(p.cur.albedo.z) | ((uint32_t)f2h(p.cur.roughness) << 16), p.rng);
+    dst[4 * n] = make_uint4(__float_as_uint(p.thr.x), __float_as_uint(p.thr.y), __float_as_uint(p.thr.z), __float_as_uint(p.pp));
+    dst[5 * n] = make_uint4(__float_as_uint(p.fval.x), __float_as_uint(p.fval.y), __float_as_uint(p.fval.z), __float_as_uint(p.m2));
+    dst[6 * n] = make_uint4(__float_as_uint(p.irr.x), __float_as_uint(p.irr.y), __float_as_uint(p.irr.z), p.px | (p.py << 16));
+    dst[7 * n] = make_uint4(__float_as_uint(p.wo.x), __float_as_uint(p.wo.y), __float_as_uint(p.wo.z), __float_as_uint(p.wo_p));
+    dst[8 * n] = make_uint4(__float_as_uint(p.bsdf), __float_as_uint(p.wodotn), __float_as_uint(p.score_sum), __float_as_uint(p.mc_sum_w));
+    dst[9 * n] = make_uint4(p.mc_index, p.mc_id, (uint32_t)p.seg | ((uint32_t)p.smp << 8) | (p.lm_dir_ok ? 0x10000u : 0u), 0u);
 }
-MQ_DEV void load_path(const uint4* src, Path& p) {
-    uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4], f = src[5], g = src[6], h = src[7], i = src[8], j = src[9];
+MQ_DEV void load_path(const uint4* src /* paths + slot */, size_t n, Path& p) {
+    uint4 a = src[0], b = src[n], c = src[2 * n], d = src[3 * n], e = src[4 * n], f = src[5 * n], g = src[6 * n], h = src[7 * n], i = src[8 * n], j = src[9 * n];
     p.cur.pos = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
     p.cur.prev_pos = F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
     p.cur.wi = F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
@@ -870,11 +876,10 @@ MQ_DEV uint32_t queue_append(const MqFrame& F, int round, bool& push) {
 }
 MQ_DEV void emit_ray(const MqFrame& F, int round, uint32_t q, uint32_t slot, const Path& p) {
     f3 ro = p.cur.pos - p.cur.wi * 1e-3f; // mcpg.comp:144
-    float4* r = F.rays + 2 * (size_t)q;
-    r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-    r[1] = make_float4(p.wo.x, p.wo.y, p.wo.z, 0.0f);
+    F.rays[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);               // origins, then directions (field-major like the path records)
+    F.rays[(size_t)F.ray_cap + q] = make_float4(p.wo.x, p.wo.y, p.wo.z, 0.0f);
     F.queue_slots[round & 1][q] = slot;
-    store_path(F.paths + 10 * (size_t)slot, p);
+    store_path(F.paths + slot, F.n_slots, p);
 }
 
 // ---- first hit: gbuffer.comp:75-131 + start of mcpg.comp:39-57 --------------------------------
@@ -915,7 +920,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 f3 ro = cam_pos(U);
                 f3 rd = camera_ray_dir((float)p.px, (float)p.py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
                 RayHit rhit;
-                traverse<COUNT>(sc, ro, rd, MQ_T_MAX, rhit, stk, spill, ctr);
+                traverse<COUNT>(sc, ro, rd, rhit, stk, spill, ctr);
                 PLAP(ctr, 1);
                 Hit h; h.pos = ro; h.wi = rd; h.prev_pos = ro; h.normal = F3(0, 0, 1); h.enc_geonormal = 0; h.albedo = F3(0, 0, 0); h.roughness = 0.0f;
                 f3 incident = F3(0, 0, 0), cthr = F3(1, 1, 1);
@@ -1004,10 +1009,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     const uint32_t per_wave = n_eff / (gridDim.x * MQ_WAVES);
     const uint32_t nblk = per_wave >= 64u * MQ_TRACE_BLOCKS ? MQ_TRACE_BLOCKS : (per_wave >= 128u && MQ_TRACE_BLOCKS >= 2u ? 2u : 1u);
     bool exhausted = false;
-    bool busy = false;
-    uint32_t q = 0;
+    uint32_t q = MQ_NIL; // queue position of the lane's ray; MQ_NIL = the lane is idle
+#define busy (q != MQ_NIL)
+#ifdef MQ_PROF
+    uint32_t ray_iters = 0;
+#endif
     Trav t;
-    trav_init(t, F3(0, 0, 0), F3(0, 0, 1), 0.0f);
+    trav_init(t, F3(0, 0, 0), F3(0, 0, 1));
     PSTART(ctr);
     for (;;) {
         unsigned long long idle = __ballot(!busy);
@@ -1046,11 +1054,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             if (!busy && rank < avail) {
                 const uint32_t i = pool_i + rank;
-                q = shard_pos(pool_s, (pool_j << 6) + i);
-                float4 o = F.rays[2 * (size_t)q], d = F.rays[2 * (size_t)q + 1];
-                trav_init(t, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z), MQ_T_MAX);
-                busy = true;
+                q = shard_pos(pool_s, (pool_j << 6) + i); // the lane is busy from here on
+                float4 o = F.rays[q], d = F.rays[(size_t)F.ray_cap + q];
+                trav_init(t, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z));
                 if (COUNT) ctr.rays++;
+#ifdef MQ_PROF
+                ray_iters = 0;
+#endif
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             pool_i += n_idle < avail ? n_idle : avail;
@@ -1060,7 +1070,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
         // node phase: lanes without pending triangles visit one node
         const bool want_node = busy && t.tmask == 0;
 #ifdef MQ_PROF
-        { const uint32_t nn = (uint32_t)__popcll(__ballot(want_node)); if (nn) { ctr.prof[12]++; ctr.prof[13] += nn; } ctr.prof[11]++; ctr.prof[30] += (uint32_t)__popcll(__ballot(busy)); }
+        { const uint32_t nn = (uint32_t)__popcll(__ballot(want_node)), nb = (uint32_t)__popcll(__ballot(busy)); if (nn) { ctr.prof[12]++; ctr.prof[13] += nn; } ctr.prof[11]++; ctr.prof[30] += nb;
+          if (exhausted && pool_i == pool_len) { ctr.prof[22]++; ctr.prof[23] += nb; } }
 #endif
         if (want_node) trav_node<COUNT>(sc, t, stk, spill, ctr);
         PLAP(ctr, 27);
@@ -1077,10 +1088,16 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
             if (has_tri) trav_tri<COUNT>(sc, t, ctr);
         }
         PLAP(ctr, 28);
+#ifdef MQ_PROF
+        if (busy) ray_iters++;
+#endif
         if (busy && t.tmask == 0) {
             if (trav_next(t, stk, spill)) {
                 F.ray_hits[q] = make_uint4(t.hit.tri, __float_as_uint(t.hit.t), __float_as_uint(t.hit.u), __float_as_uint(t.hit.v));
-                busy = false;
+                q = MQ_NIL;
+#ifdef MQ_PROF
+                atomicAdd(&F.counters->ray_hist[ray_iters / 8u < 63u ? ray_iters / 8u : 63u], 1ull);
+#endif
             }
         }
         PLAP(ctr, 29);
@@ -1096,6 +1113,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
         }
     }
 }
+#undef busy
 
 // ---- a bounce ray returned: mcpg.comp:141-189, then the next direction ---------------------------
 template <bool GUIDED, bool COUNT>
@@ -1119,7 +1137,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
         const bool valid = queue_valid(qv, q < n ? q : 0u);
         if (q < n && valid) {
             slot = F.queue_slots[round & 1][q];
-            load_path(F.paths + 10 * (size_t)slot, p);
+            load_path(F.paths + slot, F.n_slots, p);
             uint4 hq = F.ray_hits[q];
             RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
             Hit next; next.wi = p.wo; next.pos = p.cur.pos - p.cur.wi * 1e-3f; next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
@@ -1182,16 +1200,16 @@ struct VPath {
     uint32_t rng, mc_index, mc_id, px, py;
     bool lm_dir_ok;
 };
-MQ_DEV void store_vpath(uint4* d, const VPath& v) {
-    d[0] = make_uint4(__float_as_uint(v.irr.x), __float_as_uint(v.irr.y), __float_as_uint(v.irr.z), __float_as_uint(v.m2));
-    d[1] = make_uint4(v.rng, __float_as_uint(v.t), __float_as_uint(v.pd), __float_as_uint(v.wo_p));
-    d[2] = make_uint4(__float_as_uint(v.wo.x), __float_as_uint(v.wo.y), __float_as_uint(v.wo.z), __float_as_uint(v.score_sum));
-    d[3] = make_uint4(__float_as_uint(v.dist_score_sum), __float_as_uint(v.ds.sum_w), v.ds.N, __float_as_uint(v.ds.m0));
-    d[4] = make_uint4(__float_as_uint(v.ds.m1), v.mc_index, v.mc_id, __float_as_uint(v.mc_sum_w));
-    d[5] = make_uint4(v.px | (v.py << 16), v.lm_dir_ok ? 1u : 0u, 0u, 0u);
+MQ_DEV void store_vpath(uint4* d /* paths + slot */, size_t n, const VPath& v) {
+    d[0 * n] = make_uint4(__float_as_uint(v.irr.x), __float_as_uint(v.irr.y), __float_as_uint(v.irr.z), __float_as_uint(v.m2));
+    d[1 * n] = make_uint4(v.rng, __float_as_uint(v.t), __float_as_uint(v.pd), __float_as_uint(v.wo_p));
+    d[2 * n] = make_uint4(__float_as_uint(v.wo.x), __float_as_uint(v.wo.y), __float_as_uint(v.wo.z), __float_as_uint(v.score_sum));
+    d[3 * n] = make_uint4(__float_as_uint(v.dist_score_sum), __float_as_uint(v.ds.sum_w), v.ds.N, __float_as_uint(v.ds.m0));
+    d[4 * n] = make_uint4(__float_as_uint(v.ds.m1), v.mc_index, v.mc_id, __float_as_uint(v.mc_sum_w));
+    d[5 * n] = make_uint4(v.px | (v.py << 16), v.lm_dir_ok ? 1u : 0u, 0u, 0u);
 }
-MQ_DEV void load_vpath(const uint4* s, VPath& v) {
-    uint4 a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5];
+MQ_DEV void load_vpath(const uint4* s /* paths + slot */, size_t n, VPath& v) {
+    uint4 a = s[0], b = s[n], c = s[2 * n], d = s[3 * n], e = s[4 * n], f = s[5 * n];
     v.irr = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)); v.m2 = __uint_as_float(a.w);
     v.rng = b.x; v.t = __uint_as_float(b.y); v.pd = __uint_as_float(b.z); v.wo_p = __uint_as_float(b.w);
     v.wo = F3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)); v.score_sum = __uint_as_float(c.w);
@@ -1274,7 +1292,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kerne
             if (px < F.W && py < F.H) {
                 const size_t pidx = (size_t)py * F.W + px;
                 if (smp == 0) { v.px = px; v.py = py; v.irr = F3(0, 0, 0); v.m2 = 0.0f; v.rng = pcg4d16(px, py, U.frame, P.seed); } // :45
-                else load_vpath(F.paths + 10 * (size_t)my, v);
+                else load_vpath(F.paths + my, F.n_slots, v);
                 uint4 gb = *(const uint4*)(F.gbuffer + 4 * pidx);
                 const float linear_z = __uint_as_float(gb.y);
                 first_wi = camera_ray_dir((float)px, (float)py, Wf, Hf, F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]), P.fov_tan_alpha_half);
@@ -1368,15 +1386,14 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kerne
                     if (mc_index != MQ_NIL) v.lm_dir_ok = !(dot(wo, mc_state_dir(sel, cur_pos)) < 0.9f + 0.1f * mc_state_mean_cos(P, sel, cur_pos));
                     cont = true;
                 }
-                store_vpath(F.paths + 10 * (size_t)my, v);
+                store_vpath(F.paths + my, F.n_slots, v);
             }
         }
         uint32_t q = queue_append(F, round, cont);
         if (cont) {
             f3 ro = cam_pos(U) + first_wi * v.t;
-            float4* r = F.rays + 2 * (size_t)q;
-            r[0] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-            r[1] = make_float4(v.wo.x, v.wo.y, v.wo.z, 0.0f);
+            F.rays[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+            F.rays[(size_t)F.ray_cap + q] = make_float4(v.wo.x, v.wo.y, v.wo.z, 0.0f);
             F.queue_slots[round & 1][q] = my;
         }
     }
@@ -1402,7 +1419,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel
         if (!(q < n && valid)) continue;
         const uint32_t slot = F.queue_slots[round & 1][q];
         VPath v;
-        load_vpath(F.paths + 10 * (size_t)slot, v);
+        load_vpath(F.paths + slot, F.n_slots, v);
         const size_t pidx = (size_t)v.py * F.W + v.px;
         const f3 first_wi = camera_ray_dir((float)v.px, (float)v.py, Wf, Hf, F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]), P.fov_tan_alpha_half);
         const f3 cur_pos = cam_pos(U) + first_wi * v.t;
@@ -1439,7 +1456,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel
                 F.mc[v.mc_index].sum_w = 0.0f; // :228
             }
         }
-        store_vpath(F.paths + 10 * (size_t)slot, v);
+        store_vpath(F.paths + slot, F.n_slots, v);
     }
     if (COUNT) flush_counters(F.counters, ctr);
 }
@@ -1451,7 +1468,7 @@ __global__ void mq_volume_finish_kernel(MqParams P, MqFrame F) { // volume.comp:
         uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
         uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
         if (px >= F.W || py >= F.H) continue;
-        uint4 a = F.paths[10 * (size_t)my];
+        uint4 a = F.paths[my];
         *(float4*)(F.volume + 4 * ((size_t)py * F.W + px)) = make_float4(__uint_as_float(a.x) * inv, __uint_as_float(a.y) * inv, __uint_as_float(a.z) * inv, __uint_as_float(a.w) * inv);
     }
 }
@@ -1586,7 +1603,7 @@ __global__ __launch_bounds__(MQ_BLOCK) void mq_trace_kernel(MqSceneDev sc, const
     Ctr ctr = {};
     for (uint32_t i = gid; i < n; i += gridDim.x * MQ_BLOCK) {
         RayHit h;
-        traverse<false>(sc, F3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), F3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), MQ_T_MAX, h, stk, spill_base + (size_t)gid * MQ_SPILL_ENTRIES, ctr);
+        traverse<false>(sc, F3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), F3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), h, stk, spill_base + (size_t)gid * MQ_SPILL_ENTRIES, ctr);
         prim[i] = h.tri == MQ_NIL ? MQ_NIL : sc.tris[h.tri].key;
         t_out[i] = h.tri == MQ_NIL ? MQ_T_MAX : h.t;
         if (uv) { uv[2 * i] = h.u; uv[2 * i + 1] = h.v; }
@@ -1622,6 +1639,9 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
     case 14: { f3 wi = F3(a[0], a[1], a[2]); f3 w = draine_sample(a[5], a[6], wi, a[3], a[4]); o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = draine_eval(dot(wi, w), a[3], a[4]); break; }
     case 15: { float xm = transmittance_xi_max(a[1], a[0]); o[0] = transmittance_sample2(a[0], a[2], xm); o[1] = transmittance_pdf2(o[0], a[0], xm);
         o[2] = sample_normal_box_muller(a[3], a[4], a[5], a[6]); o[3] = sample_normal_pdf(a[3], a[4], o[2]); break; }
+    case 17: { mq_uniform U = {}; U.sky_rt_bk = __float_as_uint(a[3]); U.sky_lf_ft = __float_as_uint(a[4]); U.sky_up_dn = __float_as_uint(a[5]); U.cl_time = a[6];
+        f3 s = get_sky(sc, P, U, F3(a[0], a[1], a[2]), F3(P.sun_color[0], P.sun_color[1], P.sun_color[2])); o[0] = s.x; o[1] = s.y; o[2] = s.z; break; }
+    case 16: { f4 x = tex_sample(sc, (uint32_t)a[0], a[1], a[2]); o[0] = x.r; o[1] = x.g; o[2] = x.b; o[3] = x.a; break; }
     }
 }
 

@@ -160,8 +160,7 @@ struct MqSceneDev {
     const MqShadeRec* shade; // one per triangle, same order as tris
     MqGeoDev geo[MQ_MAX_GEOMETRIES];
     const MqTexDesc* tex;
-    const uint32_t* texels;
-    const float* srgb_lut; // 256 entries
+    const float4* texels; // linear RGBA32F, decoded at commit
     uint32_t n_nodes, n_tris;
 };
 
@@ -173,6 +172,7 @@ struct MqCountersDev {
     unsigned long long rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels, lc_ok, lc_cancel, q_rays, q_nodes, q_tris, q_paths;
     unsigned long long prof[MQ_PROF_SECTIONS]; // -DMQ_PROF builds: shader clocks per code section, summed over waves
+    unsigned long long ray_hist[64];           // -DMQ_PROF builds: rays by loop iterations spent in the queue kernel (bins of 8)
 };
 
 // Per-frame launch block of the render kernel.
@@ -207,7 +207,8 @@ struct MqFrame {
     uint32_t* ctrl;
     // wavefront state: 160-byte path records per pixel slot, rays / hits per queue position,
     // ping-pong queues of pixel slots
-    uint4* paths;
+    uint4* paths;          // field-major: field k of pixel slot s at paths[k * n_slots + s]
+    uint32_t n_slots;      // pixel slots of this rank (tiles * 64)
     float4* rays;
     uint4* ray_hits;
     uint32_t* queue_slots[2];

@@ -1190,7 +1190,7 @@ int orc_trace_rays(orc_ctx* c, const float* org, const float* dir, uint32_t n, u
     return 0;
 }
 
-static const int k_arity[ORC_OP_COUNT][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}};
+static const int k_arity[ORC_OP_COUNT][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}, {3, 4}, {7, 3}};
 int orc_op_arity(int op, int* n_in, int* n_out) {
     if (op < 0 || op >= ORC_OP_COUNT) return -1;
     *n_in = k_arity[op][0]; *n_out = k_arity[op][1];
@@ -1227,6 +1227,9 @@ int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n) {
             o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = orc_draine_eval(vdot(wi, w), a[3], a[4]); break; }
         case ORC_OP_DISTANCE: { float xm = orc_transmittance_xi_max(a[1], a[0]); o[0] = orc_transmittance_sample2(a[0], a[2], xm); o[1] = orc_transmittance_pdf2(o[0], a[0], xm);
             o[2] = orc_sample_normal_box_muller(a[3], a[4], a[5], a[6]); o[3] = orc_sample_normal_pdf(a[3], a[4], o[2]); break; }
+        case ORC_OP_SKY_TEX: { orc_uniform_t save = c->u; c->u.sky_rt_bk = f2u(a[3]); c->u.sky_lf_ft = f2u(a[4]); c->u.sky_up_dn = f2u(a[5]); c->u.cl_time = a[6];
+            v3 s = get_sky(c, V3(a[0], a[1], a[2]), V3(c->p.sun_color[0], c->p.sun_color[1], c->p.sun_color[2])); c->u = save; o[0] = s.x; o[1] = s.y; o[2] = s.z; break; }
+        case ORC_OP_TEX_SAMPLE: { v4 x = tex_sample(c, (uint32_t)a[0], a[1], a[2]); o[0] = x.r; o[1] = x.g; o[2] = x.b; o[3] = x.a; break; }
         }
     }
     return 0;

@@ -165,7 +165,9 @@ enum {
     ORC_OP_CAMERA = 13,     /* px py W H fwd3 up3 tan (11) -> dir3 + pixel2 roundtrip (5) */
     ORC_OP_DRAINE = 14,     /* wi3 g a xi2 (7) -> wo3, pdf (4) */
     ORC_OP_DISTANCE = 15,   /* mu_t tmax xi, gauss mu sigma xi2 (7) -> t, pdf_t, gauss x, gauss pdf (4) */
-    ORC_OP_COUNT = 16
+    ORC_OP_TEX_SAMPLE = 16, /* texnum-as-float s t (3) -> rgba (4): REPEAT addressing, nearest / bilinear, sRGB decode */
+    ORC_OP_SKY_TEX = 17,    /* w3, sky_rt_bk sky_lf_ft sky_up_dn (punned u32), cl_time (7) -> rgb (3): textured skies */
+    ORC_OP_COUNT = 18
 };
 int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n);
 int orc_op_arity(int op, int* n_in, int* n_out);

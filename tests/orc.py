@@ -9,9 +9,9 @@ LIB = os.path.join(ROOT, "oracle", "libmqoracle.so")
 
 (OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_VOLUME, OUT_VOLUME_DEPTH, OUT_VOLUME_MV) = range(9)
 (OP_EXP2, OP_LOG2, OP_SINCOS2PI, OP_POW, OP_F2H2F, OP_ENC_DEC_NORMAL, OP_BSDF_SAMPLE, OP_VMF_SAMPLE, OP_XORSHIFT,
- OP_PCG4D16, OP_SKY, OP_HASHGRID, OP_LDR_TO_HDR, OP_CAMERA, OP_DRAINE, OP_DISTANCE) = range(16)
+ OP_PCG4D16, OP_SKY, OP_HASHGRID, OP_LDR_TO_HDR, OP_CAMERA, OP_DRAINE, OP_DISTANCE, OP_TEX_SAMPLE, OP_SKY_TEX) = range(18)
 OP_ARITY = {0: (1, 1), 1: (1, 1), 2: (1, 2), 3: (2, 1), 4: (1, 1), 5: (3, 4), 6: (10, 5), 7: (6, 4), 8: (1, 4), 9: (4, 1),
-            10: (3, 3), 11: (9, 2), 12: (3, 3), 13: (11, 5), 14: (7, 4), 15: (7, 4)}
+            10: (3, 3), 11: (9, 2), 12: (3, 3), 13: (11, 5), 14: (7, 4), 15: (7, 4), 16: (3, 4), 17: (7, 3)}
 
 
 class Params(C.Structure):

@@ -81,6 +81,53 @@ def rand_inputs(op, n, rng):
     return np.ascontiguousarray(x, np.float32)
 
 
+def test_texture_sampling_bit_exact(gpu_ctx):
+    """Every texture of a scene samples to the same bits on the device (texel pool decoded at commit) and in
+    the oracle (decode per fetch): REPEAT wrap incl. negative and large coordinates, nearest and bilinear,
+    sRGB and linear textures, empty slots (grey) and out-of-range texture numbers (clamped)."""
+    rng = np.random.default_rng(7)
+    ctx = gpu_ctx
+    for scene in ("synth_tiny_fog", "synth_start"):
+        ctx.header_defaults()
+        ctx.synth_scene(scene, 5)
+        ctx.commit()
+        o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))
+        orc.mirror_scene(ctx, o)
+        o.commit(1)
+        n = 200000
+        x = np.empty((n, 3), np.float32)
+        slots = [t for t in range(4096) if ctx.get_texture(t) is not None]
+        assert len(slots) > 3
+        x[:, 0] = rng.choice(np.array(slots + [0, 1, 4094, 4095], np.float32), n)  # every texture of the scene + empty slots
+        x[: n // 100, 0] = rng.integers(4000, 5000, n // 100)  # beyond the table: clamped to the last slot
+        x[:, 1:] = rng.uniform(-3.0, 3.0, (n, 2))
+        x[: n // 10, 1:] = np.round(x[: n // 10, 1:] * 64) / 64  # texel centres and edges exactly
+        x[n // 10: n // 5, 1:] *= 1000.0
+        ref = o.math_eval(orc.OP_TEX_SAMPLE, x)
+        got = ctx.math_eval(orc.OP_TEX_SAMPLE, x, 4)
+        bad = (got.view(np.uint32) != ref.view(np.uint32)).any(-1)
+        assert bad.sum() == 0, "%s: %d mismatching samples, first %r got %r ref %r" % (scene, bad.sum(), x[np.argmax(bad)], got[np.argmax(bad)], ref[np.argmax(bad)])
+        assert (ref[:, :3].std(0) > 0).all()
+        # textured skies (raytrace.glsl:25-65): the scrolling two-layer sky and the six-sided sky box
+        u = ctx.synth_camera(90)
+        m = 100000
+        y = np.empty((m, 7), np.float32)
+        w = rng.normal(size=(m, 3)); w /= np.linalg.norm(w, axis=1, keepdims=True)
+        y[:, :3] = w
+        two = (slots[0] & 0xffff) | (slots[1] << 16)
+        y[: m // 2, 3:6] = np.array([two, 0xffff, 0xffffffff], np.uint32).view(np.float32)
+        box = [(slots[i % len(slots)] & 0xffff) | (slots[(i + 1) % len(slots)] << 16) for i in (0, 2, 4)]
+        y[m // 2:, 3:6] = np.array(box, np.uint32).view(np.float32)
+        y[:, 6] = rng.uniform(0.0, 60.0, m)
+        if u.sky_rt_bk != 0xffffffff:  # the scene's own sky words too
+            y[: m // 4, 3:6] = np.array([u.sky_rt_bk, u.sky_lf_ft, u.sky_up_dn], np.uint32).view(np.float32)
+            y[: m // 4, 6] = u.cl_time
+        ref = o.math_eval(orc.OP_SKY_TEX, y)
+        got = ctx.math_eval(orc.OP_SKY_TEX, y, 3)
+        bad = (got.view(np.uint32) != ref.view(np.uint32)).any(-1)
+        assert bad.sum() == 0, "%s sky: %d mismatching directions, first %r got %r ref %r" % (scene, bad.sum(), y[np.argmax(bad)], got[np.argmax(bad)], ref[np.argmax(bad)])
+
+
 @pytest.mark.parametrize("op", range(16))
 def test_math_primitives_bit_exact(gpu_ctx, op):
     """Every shading primitive evaluates to the same bits on the device and in the oracle."""

@@ -38,11 +38,23 @@ def main():
     clk = ctx.section_clocks()
     # lane utilisation counters of the trace loop (not clocks)
     it, nb, n_exec, n_lanes, t_exec, t_lanes = clk[11], clk[30], clk[12], clk[13], clk[14], clk[15]
-    for i in (11, 12, 13, 14, 15, 30):
+    dr_it, dr_lanes = clk[22], clk[23]
+    for i in (11, 12, 13, 14, 15, 22, 23, 30):
         clk[i] = 0
     if it:
         print(f"trace loop: {it} iterations, busy lanes {nb / it:.1f}/64; node phase ran in {100 * n_exec / it:.0f} % with {n_lanes / max(n_exec, 1):.1f} lanes; "
               f"triangle phase ran in {100 * t_exec / it:.0f} % with {t_lanes / max(t_exec, 1):.1f} lanes")
+        print(f"   drain (queue exhausted, pool empty): {100 * dr_it / it:.0f} % of the iterations with {dr_lanes / max(dr_it, 1):.1f} busy lanes; "
+              f"before the drain {(nb - dr_lanes) / max(it - dr_it, 1):.1f} busy lanes")
+    hist = clk[32:96]; clk = clk[:32]
+    if sum(hist):
+        n = float(sum(hist)); acc = 0; marks = {}
+        for b, h in enumerate(hist):
+            acc += h
+            for q in (0.5, 0.9, 0.99, 0.999):
+                if q not in marks and acc >= q * n: marks[q] = 8 * (b + 1)
+        mean = sum((8 * b + 4) * h for b, h in enumerate(hist)) / n
+        print(f"   loop iterations per ray: mean {mean:.1f}, median <= {marks[0.5]}, 90 % <= {marks[0.9]}, 99 % <= {marks[0.99]}, 99.9 % <= {marks[0.999]}, last bin (>= 504): {hist[63]}")
     tot = float(sum(clk)) or 1.0
     for g, ids in GROUPS.items():
         gs = sum(clk[i] for i in ids)
