@@ -198,10 +198,13 @@ def test_oracle_bvh_equals_brute_force(gpu_ctx):
     ("synth_tiny", 72, 40, {"spp": 3, "max path length": 4}),
     ("synth_start", 160, 120, {"spp": 1}),
     ("synth_start", 96, 64, {"spp": 2, "max path length": 2, "hide sun": 0}),
+    ("synth_start_fog", 320, 200, {"spp": 1}),
+    ("synth_sepulcher", 256, 144, {"spp": 1, "max path length": 4}),
 ])
 def test_reference_mode_frame_parity(gpu_ctx, scene, W, H, props):
     """Deterministic (unguided) frame: every output of both nodes matches the oracle.
-    Tolerance: per-pixel L2 over RGB < 1e-3 (north_star); integer/half outputs bit-exact."""
+    Tolerance: per-pixel L2 over RGB < 1e-3 (north_star); asserted stronger: the radiance image is
+    bit-identical too (same IEEE operation order, two-step half rounding), as are the integer/half outputs."""
     ctx = gpu_ctx
     o = make_pair(ctx, scene, 11, {"reference mode": 1, **props}, W, H)
     for frame in (0, 1, 7):
@@ -213,6 +216,8 @@ def test_reference_mode_frame_parity(gpu_ctx, scene, W, H, props):
         assert np.isfinite(img).all()
         assert l2.max() < 1e-3, "frame %d: max per-pixel L2 %g at %r" % (frame, l2.max(), np.unravel_index(l2.argmax(), l2.shape))
         assert np.allclose(img[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
+        bad = (img.view(np.uint32) != ref.view(np.uint32)).any(-1)
+        assert not bad.any(), "frame %d: %d pixels not bit-identical, first at %r: %r vs %r" % (frame, bad.sum(), np.argwhere(bad)[0], img[bad][0], ref[bad][0])
         import mqhip
         for which_g, which_o in ((mqhip.OUT_HITS, orc.OUT_HITS), (mqhip.OUT_GB_ALBEDO, orc.OUT_GB_ALBEDO), (mqhip.OUT_GB_IRRADIANCE, orc.OUT_GB_IRRADIANCE),
                                  (mqhip.OUT_GB_MV, orc.OUT_GB_MV), (mqhip.OUT_GBUFFER, orc.OUT_GBUFFER)):
