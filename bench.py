@@ -142,10 +142,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     tiles, tile_bytes = ctx.tiles_per_rank()
     tiles_ptr, _ = ctx.map_output(mqhip.OUT_TILES)
-    local = gathered = None
+    local = gathered = vlocal = vgathered = None
     if world > 1:
         local = torch.as_tensor(_DevArray(tiles_ptr, tile_bytes // 4), device="cuda")
         gathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
+        if args.volume_spp > 0:  # configs with volumes exchange the "volume" image too
+            vptr, _ = ctx.map_output(mqhip.OUT_VOLUME_TILES)
+            vlocal = torch.as_tensor(_DevArray(vptr, tile_bytes // 4), device="cuda")
+            vgathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
 
     def step(frame):
         ctx.process(ctx.synth_camera(frame), True, stream)
@@ -158,6 +162,14 @@ def main():
             else:
                 dist.all_gather_into_tensor(gathered, local)  # the one exchange step: RCCL over xGMI
             ctx.untile(gathered.data_ptr(), stream)
+            if vlocal is not None:
+                if rehearsal:
+                    g_cpu = torch.empty(vgathered.numel(), dtype=torch.float32)
+                    dist.all_gather_into_tensor(g_cpu, vlocal.cpu())
+                    vgathered.copy_(g_cpu)
+                else:
+                    dist.all_gather_into_tensor(vgathered, vlocal)
+                ctx.untile_volume(vgathered.data_ptr(), stream)
 
     def sync_all():
         if world > 1:
@@ -218,6 +230,7 @@ def main():
     traffic, traffic_src = pmc_traffic(dom, default_workload)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
+                "achievable_peak": round(ctx.measure_stream_read(), 1),  # streaming read of 2 GiB on this GPU, GB/s (the 8 TB/s above is the spec figure)
                 "kernel_ms_per_launch": round(dom_ms_per_launch, 4), "launches_per_frame": launches[dom],
                 "algorithmic_bytes_per_launch": int(dom_bytes_per_launch),
                 "frame": {"algorithmic_bytes": int(B), "render_ms": round(pipeline_ms, 4), "achieved": round(B / (pipeline_ms * 1e-3) / 1e9, 1),
@@ -232,7 +245,7 @@ def main():
            "config": {"workload": "%s(seed=%d) stand-in for ad_sepulcher, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
                                   % (args.scene, args.scene_seed, W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
                       "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world,
-                      "collective": "none" if world == 1 else "1x RCCL all_gather of %d B/rank per frame" % tile_bytes},
+                      "collective": "none" if world == 1 else "%dx RCCL all_gather of %d B/rank per frame" % (2 if args.volume_spp > 0 else 1, tile_bytes)},
            "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, args.scene, args.scene_seed, props, 960, 540, 6, 10)

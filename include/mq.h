@@ -93,6 +93,7 @@ enum {
     MQ_OUT_VOLUME = 7,        /* "volume" RGBA32F: single-scatter radiance + 2nd moment, render_mcpg.cpp:44-45 */
     MQ_OUT_VOLUME_DEPTH = 8,  /* "volume_depth" R16F, render_mcpg.cpp:46-47 */
     MQ_OUT_VOLUME_MV = 9,     /* "volume_mv" RG16F, render_mcpg.cpp:48-50 */
+    MQ_OUT_VOLUME_TILES = 10, /* this rank's "volume" tiles, tile-major (second multi-GPU exchange buffer, configs with volume spp > 0) */
     MQ_OUT_COUNT
 };
 
@@ -201,10 +202,15 @@ int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 int mq_set_partition(mq_ctx* ctx, int rank, int world);
 int mq_tiles_per_rank(const mq_ctx* ctx, uint32_t* tiles, size_t* bytes);
 int mq_untile(mq_ctx* ctx, const void* gathered_dev, void* stream);
+/* the same for the gathered MQ_OUT_VOLUME_TILES buffers -> MQ_OUT_VOLUME */
+int mq_untile_volume(mq_ctx* ctx, const void* gathered_dev, void* stream);
 
 /* ---- closest-hit ray queries against the committed scene (raytrace.glsl:82-119 semantics) ---- */
 int mq_trace_rays(mq_ctx* ctx, const float* org_host, const float* dir_host, uint32_t n,
                   uint32_t* prim_host, float* t_host, float* uv_host);
+/* achievable HBM read rate of this GPU: best of `reps` passes of a streaming-read kernel over a
+ * fresh `bytes`-sized buffer (use >= 1 GiB: beyond the 256 MB Infinity Cache), in GB/s */
+int mq_measure_stream_read(mq_ctx* ctx, size_t bytes, int reps, double* gb_per_s);
 /* device-side evaluation of the shading primitives, for known-answer tests against the oracle */
 int mq_math_eval(mq_ctx* ctx, int op, const float* in_host, float* out_host, uint32_t n);
 

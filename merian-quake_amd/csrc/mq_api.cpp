@@ -27,6 +27,7 @@ int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, boo
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s);
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_stack_lds_entries();
+int mq_launch_stream_read(const void* src, size_t bytes, uint32_t* sink, int grid, hipStream_t s);
 int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int out[3]);
 int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
@@ -301,7 +302,7 @@ void free_scene_dev(mq_ctx* c) {
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
 }
 
-const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4};
+const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16};
 
 void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     memset(d, 0, sizeof *d);
@@ -311,6 +312,7 @@ void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     uint32_t tpr = (nt + (uint32_t)c->world - 1) / (uint32_t)c->world;
     for (int i = 0; i < MQ_OUT_COUNT; i++) { d->bytes_per_pixel[i] = k_bpp[i]; d->bytes[i] = px * k_bpp[i]; }
     d->bytes[MQ_OUT_TILES] = (size_t)tpr * 64 * 16;
+    d->bytes[MQ_OUT_VOLUME_TILES] = (size_t)tpr * 64 * 16;
     size_t mc_total = (size_t)c->props.mc_adaptive_buffer_size + c->props.mc_static_buffer_size; // render_mcpg.cpp:59
     d->state_bytes_markovchain = mc_total * sizeof(MqMCState) + mc_total * 8; // states + per-slot count and chain head of the update queue
     d->state_bytes_lightcache = (size_t)c->props.lc_buffer_size * sizeof(MqLCCell);
@@ -683,7 +685,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     memset(&F, 0, sizeof F);
     F.u = *u; F.W = c->W; F.H = c->H; F.tiles_x = c->tiles_x; F.tiles_y = c->tiles_y;
     F.n_local_tiles = c->n_local_tiles; F.rank = (uint32_t)c->rank; F.world = (uint32_t)c->world;
-    F.irradiance = (float*)c->d_out[MQ_OUT_IRRADIANCE].p; F.tiles_out = (float*)c->d_out[MQ_OUT_TILES].p;
+    F.irradiance = (float*)c->d_out[MQ_OUT_IRRADIANCE].p; F.tiles_out = (float*)c->d_out[MQ_OUT_TILES].p; F.volume_tiles_out = (float*)c->d_out[MQ_OUT_VOLUME_TILES].p;
     F.gb_albedo = (uint16_t*)c->d_out[MQ_OUT_GB_ALBEDO].p; F.gb_irr = (uint16_t*)c->d_out[MQ_OUT_GB_IRRADIANCE].p;
     F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
@@ -795,7 +797,10 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         }
         e = mq_launch_volume_finish(c->params, F, c->grid_blocks, s);
         if (e) return fail(c, MQ_EHIP, std::string("volume finish launch: ") + hipGetErrorString((hipError_t)e));
-    } else HIPCHK(c, hipMemsetAsync(c->d_out[MQ_OUT_VOLUME].p, 0, c->d_out[MQ_OUT_VOLUME].bytes, s));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->d_out[MQ_OUT_VOLUME].p, 0, c->d_out[MQ_OUT_VOLUME].bytes, s));
+        HIPCHK(c, hipMemsetAsync(c->d_out[MQ_OUT_VOLUME_TILES].p, 0, c->d_out[MQ_OUT_VOLUME_TILES].bytes, s));
+    }
     HIPCHK(c, hipEventRecord(ev[3 + 2 * timed], s));
     c->ev_rounds[slot] = timed;
     c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
@@ -907,6 +912,16 @@ int mq_untile(mq_ctx* c, const void* gathered_dev, void* stream) {
     return MQ_OK;
 }
 
+int mq_untile_volume(mq_ctx* c, const void* gathered_dev, void* stream) {
+    if (!c || !gathered_dev) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
+    HIPCHK(c, hipSetDevice(c->device));
+    int e = mq_launch_untile(gathered_dev, c->d_out[MQ_OUT_VOLUME].p, c->W, c->H, c->tiles_x, c->tiles_x * c->tiles_y, (uint32_t)c->world, c->tiles_per_rank, (hipStream_t)stream);
+    if (e) return fail(c, MQ_EHIP, std::string("untile launch: ") + hipGetErrorString((hipError_t)e));
+    return MQ_OK;
+}
+
 // ---- queries -----------------------------------------------------------------------------------
 int mq_trace_rays(mq_ctx* c, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv) {
     if (!c || !org || !dir || !prim || !t) return MQ_EINVAL;
@@ -948,6 +963,31 @@ int mq_math_eval(mq_ctx* c, int op, const float* in, float* out, uint32_t n) {
     if (!r && hipMemcpy(out, d_out.p, (size_t)n * no * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
     dev_free(d_in); dev_free(d_out);
     return r;
+}
+
+int mq_measure_stream_read(mq_ctx* c, size_t bytes, int reps, double* gb_per_s) {
+    if (!c || !gb_per_s || reps < 1 || bytes < (1u << 20)) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf buf, sink; int r = dev_alloc(c, buf, bytes);
+    if (!r) r = dev_alloc(c, sink, 16);
+    if (r) { dev_free(buf); dev_free(sink); return r; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMemset(buf.p, 0x5a, bytes) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    const int grid = std::max(1, c->cu_count) * 16;
+    float best = 0.0f;
+    for (int i = 0; ok && i < reps + 1; i++) { // first pass warms up
+        ok = hipEventRecord(e0, nullptr) == hipSuccess && mq_launch_stream_read(buf.p, bytes, (uint32_t*)sink.p, grid, nullptr) == 0 &&
+             hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+        float ms = 0.0f;
+        if (ok) ok = hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        if (ok && i > 0 && ms > 0.0f) best = std::max(best, (float)(bytes / (ms * 1e-3) / 1e9));
+    }
+    if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+    dev_free(buf); dev_free(sink);
+    if (!ok) return fail(c, MQ_EHIP, "stream-read measurement failed");
+    *gb_per_s = best;
+    return MQ_OK;
 }
 
 // ---- scene sources -----------------------------------------------------------------------------

@@ -185,6 +185,7 @@ struct MqFrame {
     // outputs
     float* irradiance;     // W*H*4 (full image, linear index) -- written for local tiles only
     float* tiles_out;      // n_local_tiles*64*4
+    float* volume_tiles_out; // n_local_tiles*64*4: tile-major copy of `volume`
     uint16_t* gb_albedo;   // W*H*4 half
     uint16_t* gb_irr;      // W*H*4 half
     uint16_t* gb_mv;       // W*H*2 half

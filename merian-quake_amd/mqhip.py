@@ -19,7 +19,7 @@ MQ_MAX_GEOMETRIES = 16
 MQ_GEO_OPAQUE, MQ_GEO_STATIC = 1, 2
 MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
 (OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_VOLUME, OUT_VOLUME_DEPTH,
- OUT_VOLUME_MV, OUT_COUNT) = range(11)
+ OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_COUNT) = range(12)
 MQ_ENODEVICE = -2
 
 EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),
@@ -113,6 +113,7 @@ def load_library(path=None):
         "mq_timing_get": (i32, [P, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mq_timing_get_detail": (i32, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "mq_timing_get_rounds": (i32, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
+        "mq_measure_stream_read": (i32, [P, sz, i32, C.POINTER(C.c_double)]),
         "mq_enable_counters": (i32, [P, i32]),
         "mq_get_counters": (i32, [P, C.POINTER(Counters)]),
         "mq_reset_state": (i32, [P]),
@@ -120,6 +121,7 @@ def load_library(path=None):
         "mq_set_partition": (i32, [P, i32, i32]),
         "mq_tiles_per_rank": (i32, [P, u32p, C.POINTER(sz)]),
         "mq_untile": (i32, [P, vp, vp]),
+        "mq_untile_volume": (i32, [P, vp, vp]),
         "mq_trace_rays": (i32, [P, vp, vp, u32, vp, vp, vp]),
         "mq_math_eval": (i32, [P, i32, vp, vp, u32]),
         "mq_synth_scene": (i32, [P, C.c_char_p, u32]),
@@ -316,6 +318,11 @@ class Context:
         self._chk(self.lib.mq_timing_get_rounds(self.h, a, b, 9))
         return list(zip(a, b))
 
+    def measure_stream_read(self, nbytes=2 << 30, reps=5):
+        v = C.c_double()
+        self._chk(self.lib.mq_measure_stream_read(self.h, nbytes, reps, C.byref(v)))
+        return v.value
+
     def enable_counters(self, on):
         self._chk(self.lib.mq_enable_counters(self.h, 1 if on else 0))
 
@@ -343,6 +350,9 @@ class Context:
 
     def untile(self, gathered_dev_ptr, stream=None):
         self._chk(self.lib.mq_untile(self.h, gathered_dev_ptr, stream))
+
+    def untile_volume(self, gathered_dev_ptr, stream=None):
+        self._chk(self.lib.mq_untile_volume(self.h, gathered_dev_ptr, stream))
 
     def trace_rays(self, org, direction):
         org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
