@@ -79,7 +79,7 @@ typedef struct mq_constants {
 /* geometry flags: instance flags of src/game/quake_node.cpp:869-871,891-892 */
 enum { MQ_GEO_OPAQUE = 1, MQ_GEO_STATIC = 2 };
 /* texture flags: src/game/quake_node.hpp:86-108 (sRGB unless *_norm/_gloss), sampler choice */
-enum { MQ_TEX_SRGB = 1, MQ_TEX_LINEAR = 2 };
+enum { MQ_TEX_SRGB = 1, MQ_TEX_LINEAR = 2, MQ_TEX_MIPMAP = 4 /* TEXPREF_MIPMAP, quake_node.cpp:698: mip chain for the first hit's textureGrad */ };
 
 /* named outputs of the two nodes: src/render_mcpg/render_mcpg.cpp:42-52, src/gbuffer/gbuffer.cpp:27-43 */
 enum {

@@ -281,6 +281,7 @@ void props_to_params(mq_ctx* c) {
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
     P.volume_forward_project = q.volume_forward_project;
+    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap;
     P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
     for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
@@ -541,15 +542,49 @@ int mq_scene_commit(mq_ctx* c) {
             c->scene.geo[s].idx = (const uint32_t*)c->d_idx[s].p; c->scene.geo[s].prev_vtx = (const float*)c->d_prev[s].p;
         }
     }
+    // Texel pool: linear RGBA32F.  Level 0 decoded once (sRGB through the 256-entry table, quake_node.hpp:93-95,
+    // everything else x / 255: the values a per-fetch decode gives); MQ_TEX_MIPMAP textures are followed by their
+    // mip chain, level k+1 = 2x2 box filter of level k on the float texels, ((a + b) + (c + d)) * 0.25 with clamped
+    // source indices, sizes max(1, size >> 1) down to 1x1.
     std::vector<MqTexDesc> desc(MQ_MAX_GLTEXTURES);
-    std::vector<uint32_t> pool;
-    for (uint32_t t = 0; t < MQ_MAX_GLTEXTURES; t++) {
-        const MqHostTex& tx = c->tex[t];
-        if (tx.px.empty()) { desc[t].offset = MQ_NIL; desc[t].w = desc[t].h = 0; desc[t].flags = 0; continue; }
-        desc[t].offset = (uint32_t)pool.size(); desc[t].w = (uint16_t)tx.w; desc[t].h = (uint16_t)tx.h; desc[t].flags = tx.flags;
-        size_t n = (size_t)tx.w * tx.h;
-        size_t at = pool.size(); pool.resize(at + n);
-        memcpy(&pool[at], tx.px.data(), n * 4);
+    std::vector<float> lin;
+    {
+        float lut[256];
+        for (int i = 0; i < 256; i++) { double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4)); }
+        for (uint32_t t = 0; t < MQ_MAX_GLTEXTURES; t++) {
+            const MqHostTex& tx = c->tex[t];
+            if (tx.px.empty()) { desc[t].offset = MQ_NIL; desc[t].w = desc[t].h = 0; desc[t].flags = 0; continue; }
+            const bool srgb = (tx.flags & MQ_TEX_SRGB) != 0;
+            const size_t n = (size_t)tx.w * tx.h;
+            size_t at = lin.size();
+            desc[t].offset = (uint32_t)(at / 4); desc[t].w = (uint16_t)tx.w; desc[t].h = (uint16_t)tx.h;
+            lin.resize(at + 4 * n);
+            for (size_t i = 0; i < n; i++) {
+                const uint8_t* p = &tx.px[4 * i];
+                float* o = &lin[at + 4 * i];
+                for (int k = 0; k < 3; k++) o[k] = srgb ? lut[p[k]] : (float)p[k] * (1.0f / 255.0f);
+                o[3] = (float)p[3] * (1.0f / 255.0f);
+            }
+            uint32_t levels = 1;
+            if (tx.flags & MQ_TEX_MIPMAP) {
+                uint32_t pw = tx.w, ph = tx.h; size_t prev = at;
+                while ((pw > 1 || ph > 1) && levels < 16) {
+                    const uint32_t w = std::max(1u, pw >> 1), h = std::max(1u, ph >> 1);
+                    const size_t dst = lin.size();
+                    lin.resize(dst + (size_t)w * h * 4);
+                    for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) {
+                        const uint32_t x0 = std::min(2 * x, pw - 1), x1 = std::min(2 * x + 1, pw - 1), y0 = std::min(2 * y, ph - 1), y1 = std::min(2 * y + 1, ph - 1);
+                        for (int ch = 0; ch < 4; ch++) {
+                            const float a = lin[prev + 4 * ((size_t)y0 * pw + x0) + ch], b = lin[prev + 4 * ((size_t)y0 * pw + x1) + ch];
+                            const float d = lin[prev + 4 * ((size_t)y1 * pw + x0) + ch], e = lin[prev + 4 * ((size_t)y1 * pw + x1) + ch];
+                            lin[dst + 4 * ((size_t)y * w + x) + ch] = ((a + b) + (d + e)) * 0.25f;
+                        }
+                    }
+                    prev = dst; pw = w; ph = h; levels++;
+                }
+            }
+            desc[t].flags = (tx.flags & 0xffu) | (levels << 8);
+        }
     }
     if ((r = dev_upload(c, c->d_texdesc, desc.data(), desc.size() * sizeof(MqTexDesc)))) return r;
     { // shading records in BVH triangle order
@@ -566,23 +601,7 @@ int mq_scene_commit(mq_ctx* c) {
         }
         if ((r = dev_upload(c, c->d_shade, recs.data(), recs.size() * sizeof(MqShadeRec)))) return r;
     }
-    { // decode the pool once: sRGB through the 256-entry table (quake_node.hpp:93-95), everything else x / 255
-        float lut[256];
-        for (int i = 0; i < 256; i++) { double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4)); }
-        std::vector<float> lin(pool.size() * 4);
-        for (uint32_t t = 0; t < MQ_MAX_GLTEXTURES; t++) {
-            if (desc[t].offset == MQ_NIL) continue;
-            const bool srgb = (desc[t].flags & MQ_TEX_SRGB) != 0;
-            const size_t n = (size_t)desc[t].w * desc[t].h;
-            for (size_t i = 0; i < n; i++) {
-                const uint32_t p = pool[desc[t].offset + i];
-                float* o = &lin[4 * (desc[t].offset + i)];
-                for (int k = 0; k < 3; k++) { const uint32_t b = (p >> (8 * k)) & 0xffu; o[k] = srgb ? lut[b] : (float)b * (1.0f / 255.0f); }
-                o[3] = (float)(p >> 24) * (1.0f / 255.0f);
-            }
-        }
-        if ((r = dev_upload(c, c->d_texels, lin.data(), lin.size() * 4))) return r;
-    }
+    if ((r = dev_upload(c, c->d_texels, lin.data(), lin.size() * 4))) return r;
     c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p; c->scene.shade = (const MqShadeRec*)c->d_shade.p;
     c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const float4*)c->d_texels.p;
     c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
@@ -947,9 +966,9 @@ int mq_trace_rays(mq_ctx* c, const float* org, const float* dir, uint32_t n, uin
     return r;
 }
 
-static const int k_arity[18][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}, {3, 4}, {7, 3}};
+static const int k_arity[19][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}, {3, 4}, {7, 3}, {7, 4}};
 int mq_math_eval(mq_ctx* c, int op, const float* in, float* out, uint32_t n) {
-    if (!c || !in || !out || op < 0 || op >= 18) return MQ_EINVAL;
+    if (!c || !in || !out || op < 0 || op >= 19) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
     if (n == 0) return MQ_OK;
     HIPCHK(c, hipSetDevice(c->device));

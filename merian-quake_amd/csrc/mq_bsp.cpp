@@ -147,7 +147,7 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
                 continue;
             }
             m.texnum = next_tex++;
-            MqHostTex& t = mq_ctx_tex(ctx, m.texnum); t.w = m.w; t.h = m.h; t.flags = MQ_TEX_SRGB; t.px.resize(px * 4);
+            MqHostTex& t = mq_ctx_tex(ctx, m.texnum); t.w = m.w; t.h = m.h; t.flags = MQ_TEX_SRGB | (m.turb ? 0u : MQ_TEX_MIPMAP); t.px.resize(px * 4); // brush textures carry TEXPREF_MIPMAP, warped liquids do not
             bool any_fb = false;
             for (size_t k = 0; k < px; k++) {
                 uint8_t ci = src ? src[k] : (uint8_t)(((k / m.w) ^ (k % m.w)) & 8 ? 96 : 160);
@@ -158,7 +158,7 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
             }
             if (any_fb && src && !m.turb) { // fullbright mask texture: non-fullbright texels are black
                 m.fb = next_tex++;
-                MqHostTex& f = mq_ctx_tex(ctx, m.fb); f.w = m.w; f.h = m.h; f.flags = MQ_TEX_SRGB; f.px.assign(px * 4, 0);
+                MqHostTex& f = mq_ctx_tex(ctx, m.fb); f.w = m.w; f.h = m.h; f.flags = MQ_TEX_SRGB | MQ_TEX_MIPMAP; f.px.assign(px * 4, 0);
                 for (size_t k = 0; k < px; k++) {
                     uint8_t ci = src[k];
                     if (ci >= 224 && !(m.alpha && ci == 255)) { uint8_t* d = &f.px[4 * k]; d[0] = pal[3 * ci]; d[1] = pal[3 * ci + 1]; d[2] = pal[3 * ci + 2]; d[3] = 255; }

@@ -114,6 +114,46 @@ MQ_DEV f4 tex_sample(const MqSceneDev& sc, uint32_t texnum, float s, float t) {
     if (texnum > MQ_MAX_GLTEXTURES - 1) texnum = MQ_MAX_GLTEXTURES - 1;
     return tex_sample_desc(sc, sc.tex[texnum], s, t);
 }
+// ---- mip chain + textureGrad (first hit only, raytrace.glsl:232-245,299-303); definitions as in the oracle:
+// LOD from the Vulkan footprint formula, lambda <= 0 (or NaN) -> magnification path, else bilinear in the two
+// nearest levels mixed by frac(lambda).  Level k follows level k-1 in the pool.
+MQ_DEV uint32_t mip_dim(uint32_t d, uint32_t k) { uint32_t v = d >> k; return v ? v : 1u; }
+MQ_DEV f4 tex_bilinear_level(const MqSceneDev& sc, const MqTexDesc& tx, uint32_t level, float s, float t) {
+    uint32_t off = tx.offset;
+    for (uint32_t k = 0; k < level; k++) off += mip_dim(tx.w, k) * mip_dim(tx.h, k);
+    const int w = (int)mip_dim(tx.w, level), h = (int)mip_dim(tx.h, level);
+    int x0, x1, y0, y1; float fx, fy;
+    tex_linear_coord(s, (float)w, w, x0, x1, fx);
+    tex_linear_coord(t, (float)h, h, y0, y1, fy);
+    const float4 a = sc.texels[off + (uint32_t)y0 * w + (uint32_t)x0], b = sc.texels[off + (uint32_t)y0 * w + (uint32_t)x1];
+    const float4 d = sc.texels[off + (uint32_t)y1 * w + (uint32_t)x0], e = sc.texels[off + (uint32_t)y1 * w + (uint32_t)x1];
+    f4 r;
+    r.r = mmix(mmix(a.x, b.x, fx), mmix(d.x, e.x, fx), fy);
+    r.g = mmix(mmix(a.y, b.y, fx), mmix(d.y, e.y, fx), fy);
+    r.b = mmix(mmix(a.z, b.z, fx), mmix(d.z, e.z, fx), fy);
+    r.a = mmix(mmix(a.w, b.w, fx), mmix(d.w, e.w, fx), fy);
+    return r;
+}
+MQ_DEV f4 tex_sample_grad_desc(const MqSceneDev& sc, const MqTexDesc& tx, float s, float t, float dsdx, float dtdx, float dsdy, float dtdy) {
+    const uint32_t levels = (tx.flags >> 8) & 0xffu;
+    if (tx.offset == MQ_NIL || levels <= 1u) return tex_sample_desc(sc, tx, s, t);
+    const float fw = (float)tx.w, fh = (float)tx.h;
+    const float ax = dsdx * fw, ay = dtdx * fh, bx = dsdy * fw, by = dtdy * fh;
+    const float rx = sqrtf(ax * ax + ay * ay), ry = sqrtf(bx * bx + by * by);
+    const float rho = rx > ry ? rx : ry;
+    if (!(rho > 1.0f)) return tex_sample_desc(sc, tx, s, t);
+    float lambda = mq_log2(rho);
+    const float top = (float)(levels - 1u);
+    if (!(lambda < top)) lambda = top;
+    const float fl = floorf(lambda);
+    const uint32_t lo = (uint32_t)fl, hi = lo + 1u < levels ? lo + 1u : lo;
+    const float f = lambda - fl;
+    const f4 c0 = tex_bilinear_level(sc, tx, lo, s, t);
+    if (hi == lo || !(f > 0.0f)) return c0;
+    const f4 c1 = tex_bilinear_level(sc, tx, hi, s, t);
+    f4 r; r.r = mmix(c0.r, c1.r, f); r.g = mmix(c0.g, c1.g, f); r.b = mmix(c0.b, c1.b, f); r.a = mmix(c0.a, c1.a, f);
+    return r;
+}
 MQ_DEV float tex_gather_alpha_r(const MqSceneDev& sc, const MqTexDesc& tx, float s, float t) {
     if (tx.offset == MQ_NIL) return 1.0f;
     int x0, x1, y0, y1; float fx, fy;
@@ -365,8 +405,11 @@ MQ_DEV f3 get_sky(const MqSceneDev& sc, const MqParams& P, const mq_uniform& U, 
 MQ_DEV f3 ld3(const float* p, uint32_t i) { return F3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 
 // Shades the closest hit `rhit` of the ray (hit.pos, hit.wi).  Mirrors raytrace.glsl:166-311.
+// FIRST: the g-buffer's first hit (MERIAN_QUAKE_FIRST_HIT, raytrace.glsl:153-156): r_x / r_y are the directions of
+// the camera rays one pixel to the right / below and select the mip level of the albedo / emission fetch.
+template <bool FIRST = false>
 MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform& U, const RayHit& rhit,
-                      f3& throughput, f3& contribution, Hit& hit, f3 sun_color) {
+                      f3& throughput, f3& contribution, Hit& hit, f3 sun_color, f3 r_x = F3(0, 0, 0), f3 r_y = F3(0, 0, 0)) {
     float tq = rhit.tri == MQ_NIL ? MQ_T_MAX : rhit.t;
     float tr = rh(transmittance(tq, U.cam_x[3], P.volume_max_t));
     throughput = rh3(throughput * tr);
@@ -418,7 +461,28 @@ MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform&
         uint32_t i0 = g.idx[3 * prim], i1 = g.idx[3 * prim + 1], i2 = g.idx[3 * prim + 2];
         hit.prev_pos = (ld3(g.prev_vtx, i0) * b0 + ld3(g.prev_vtx, i1) * b1) + ld3(g.prev_vtx, i2) * b2;
     } else hit.prev_pos = hit.pos;
-    f4 at = tex_sample_desc(sc, tx_albedo, s, t);
+    // :232-239 texture-space footprint of the pixel: Igehy transfer of {dO = 0, dD = r} over the hit distance onto
+    // the triangle's plane, pseudoinverse of the edge matrix [du dv] by the normal equations, half-precision
+    // texture-coordinate edge differences (f16mat2 st_dudv, :208-209) -- same operation order as the oracle
+    float gxs = 0.0f, gxt = 0.0f, gys = 0.0f, gyt = 0.0f;
+    const bool use_grad = FIRST && (P.enable_albedo_mipmap || P.enable_emission_mipmap);
+    if (use_grad) {
+        const f3 n = hit.normal, D = hit.wi;
+        const float dn = dot(D, n);
+        const float a = dot(du, du), b = dot(du, dv), cc = dot(dv, dv);
+        const float det = a * cc - b * b;
+        const float d0x = rh(st2s - st0s), d0y = rh(st2t - st0t), d1x = rh(st1s - st0s), d1y = rh(st1t - st0t);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            f3 dO = (k == 0 ? r_x : r_y) * rhit.t;
+            dO = dO - D * (dot(dO, n) / dn);
+            const float pu = dot(du, dO), pv = dot(dv, dO);
+            const float ca = (cc * pu - b * pv) / det, cb = (a * pv - b * pu) / det;
+            const float gs = d0x * ca + d1x * cb, gt = d0y * ca + d1y * cb;
+            if (k == 0) { gxs = gs; gxt = gt; } else { gys = gs; gyt = gt; }
+        }
+    }
+    f4 at = (use_grad && P.enable_albedo_mipmap) ? tex_sample_grad_desc(sc, tx_albedo, s, t, gxs, gxt, gys, gyt) : tex_sample_desc(sc, tx_albedo, s, t);
     f3 albedo_tex = rh3(F3(mq_pow(rh(at.r), 1.0f / 1.2f), mq_pow(rh(at.g), 1.0f / 1.2f), mq_pow(rh(at.b), 1.0f / 1.2f)));
     if (e.n1_brush == 0xffffffffu) { // :249-274
         uint32_t tn_norm = e.n0_gloss_norm >> 16, tn_gloss = e.n0_gloss_norm & 0xffffu;
@@ -455,7 +519,7 @@ MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform&
         uint32_t fb = e.texnum_fb_flags & 0xfffu;
         hit.albedo = albedo_tex;
         if (fb > 0 && fb < MQ_MAX_GLTEXTURES) {
-            f4 ft = tex_sample_desc(sc, tx_fb, s, t);
+            f4 ft = (use_grad && P.enable_emission_mipmap) ? tex_sample_grad_desc(sc, tx_fb, s, t, gxs, gxt, gys, gyt) : tex_sample_desc(sc, tx_fb, s, t);
             f3 em = ldr_to_hdr(rh3(F3(ft.r, ft.g, ft.b)));
             if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {
                 contribution = rh3(contribution + rh3(throughput * em));
@@ -924,7 +988,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 PLAP(ctr, 1);
                 Hit h; h.pos = ro; h.wi = rd; h.prev_pos = ro; h.normal = F3(0, 0, 1); h.enc_geonormal = 0; h.albedo = F3(0, 0, 0); h.roughness = 0.0f;
                 f3 incident = F3(0, 0, 0), cthr = F3(1, 1, 1);
-                shade_hit(sc, P, U, rhit, cthr, incident, h, gb_sun);
+                const f3 r_x = camera_ray_dir((float)p.px + 1.0f, (float)p.py, Wf, Hf, up, fw, P.fov_tan_alpha_half); // gbuffer.comp:92-93
+                const f3 r_y = camera_ray_dir((float)p.px, (float)p.py + 1.0f, Wf, Hf, up, fw, P.fov_tan_alpha_half);
+                shade_hit<true>(sc, P, U, rhit, cthr, incident, h, gb_sun, r_x, r_y);
                 PLAP(ctr, 2);
                 *(uint2*)(F.gb_irr + 4 * pidx) = make_uint2((uint32_t)f2h(incident.x) | ((uint32_t)f2h(incident.y) << 16), (uint32_t)f2h(incident.z) | (0x3c00u << 16));
                 float keep = (incident.x >= 1e-5f || incident.y >= 1e-5f || incident.z >= 1e-5f) ? 0.0f : 1.0f; // gbuffer.comp:107
@@ -940,8 +1006,6 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 store_chit(rec, h);
                 { uint2* d2 = (uint2*)(F.hits + 10 * pidx); const uint2* s2 = (const uint2*)rec; d2[0] = s2[0]; d2[1] = s2[1]; d2[2] = s2[2]; d2[3] = s2[3]; d2[4] = s2[4]; }
                 { // gbuffer.comp:123-130
-                    f3 r_x = camera_ray_dir((float)p.px + 1.0f, (float)p.py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
-                    f3 r_y = camera_ray_dir((float)p.px, (float)p.py + 1.0f, Wf, Hf, up, fw, P.fov_tan_alpha_half);
                     f3 gn = decode_normal(h.enc_geonormal);
                     f3 cp = cam_pos(U);
                     float lz = length(cp - h.pos);
@@ -1643,6 +1707,8 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
         o[2] = sample_normal_box_muller(a[3], a[4], a[5], a[6]); o[3] = sample_normal_pdf(a[3], a[4], o[2]); break; }
     case 17: { mq_uniform U = {}; U.sky_rt_bk = __float_as_uint(a[3]); U.sky_lf_ft = __float_as_uint(a[4]); U.sky_up_dn = __float_as_uint(a[5]); U.cl_time = a[6];
         f3 s = get_sky(sc, P, U, F3(a[0], a[1], a[2]), F3(P.sun_color[0], P.sun_color[1], P.sun_color[2])); o[0] = s.x; o[1] = s.y; o[2] = s.z; break; }
+    case 18: { uint32_t tn = (uint32_t)a[0]; if (tn > MQ_MAX_GLTEXTURES - 1) tn = MQ_MAX_GLTEXTURES - 1;
+        f4 x = tex_sample_grad_desc(sc, sc.tex[tn], a[1], a[2], a[3], a[4], a[5], a[6]); o[0] = x.r; o[1] = x.g; o[2] = x.b; o[3] = x.a; break; }
     case 16: { f4 x = tex_sample(sc, (uint32_t)a[0], a[1], a[2]); o[0] = x.r; o[1] = x.g; o[2] = x.b; o[3] = x.a; break; }
     }
 }

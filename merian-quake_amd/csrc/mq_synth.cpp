@@ -154,7 +154,7 @@ struct Gen {
 void make_textures(mq_ctx* ctx, Rng& rng) {
     for (int t = 1; t <= 16; t++) { // albedo: uniform random in [32,224] with a per-texture tint
         MqHostTex& tx = mq_ctx_tex(ctx, (uint32_t)t);
-        tx.w = tx.h = 64; tx.flags = MQ_TEX_SRGB | ((t & 1) ? MQ_TEX_LINEAR : 0u);
+        tx.w = tx.h = 64; tx.flags = MQ_TEX_SRGB | MQ_TEX_MIPMAP | ((t & 1) ? MQ_TEX_LINEAR : 0u); // world textures carry TEXPREF_MIPMAP
         tx.px.resize(64 * 64 * 4);
         float tint[3] = {0.6f + 0.4f * rng.uni(), 0.6f + 0.4f * rng.uni(), 0.6f + 0.4f * rng.uni()};
         for (int i = 0; i < 64 * 64; i++) {
@@ -164,7 +164,7 @@ void make_textures(mq_ctx* ctx, Rng& rng) {
         }
     }
     { // fullbright: values in [0.5, 1]
-        MqHostTex& tx = mq_ctx_tex(ctx, TEX_FB); tx.w = tx.h = 64; tx.flags = MQ_TEX_SRGB; tx.px.resize(64 * 64 * 4);
+        MqHostTex& tx = mq_ctx_tex(ctx, TEX_FB); tx.w = tx.h = 64; tx.flags = MQ_TEX_SRGB | MQ_TEX_MIPMAP; tx.px.resize(64 * 64 * 4);
         for (int i = 0; i < 64 * 64; i++) { int v = 128 + rng.range(128); tx.px[4 * i] = (uint8_t)v; tx.px[4 * i + 1] = (uint8_t)(v * 0.9f); tx.px[4 * i + 2] = (uint8_t)(v * 0.7f); tx.px[4 * i + 3] = 255; }
     }
     for (int layer = 0; layer < 2; layer++) { // classic two-layer sky (back solid, front with alpha holes)

@@ -60,7 +60,7 @@ static_assert(sizeof(MqTri) == 48, "triangle must be 48 bytes");
 struct MqTexDesc {
     uint32_t offset; // texel offset into the texel pool; MQ_NIL if the slot is empty
     uint16_t w, h;
-    uint32_t flags;
+    uint32_t flags;  // MQ_TEX_* in bits 0..7; number of mip levels (>= 1) in bits 8..15, level k follows level k-1 in the pool
 };
 
 // 64-byte shading record per triangle, in BVH triangle order (same index as MqTri): the triangle's
@@ -141,6 +141,7 @@ struct MqParams {
     int32_t gbuffer_hide_sun, quirk_lc_max_wo_p, quirk_n16_wrap;
     int32_t debug_output_selector;
     int32_t volume_forward_project;
+    int32_t enable_albedo_mipmap, enable_emission_mipmap; // g-buffer node, gbuffer.cpp:49-50,79-81
     // derived on the host with the same float operations the kernels would use (mq_api.cpp props_to_params)
     float mc_static_inv_width;
     float mc_inv_width_lut[MQ_WIDTH_LUT]; // 1 / width(level) of the adaptive MC grid

@@ -47,7 +47,8 @@ typedef struct {
     uint32_t* idx; orc_ext_t* ext; uint32_t n_tri; uint32_t flags;
 } geo_t;
 
-typedef struct { uint32_t w, h, flags; uint8_t* px; } tex_t;
+/* mip: levels 1.. of the chain as linear RGBA32F, level k at mip + mip_off[k] floats (NULL without ORC_TEX_MIPMAP) */
+typedef struct { uint32_t w, h, flags; uint8_t* px; uint32_t levels; float* mip; size_t mip_off[16]; } tex_t;
 
 typedef struct { v3 v0, v1, v2; uint32_t key; uint32_t opaque; } tri_t;
 typedef struct { v3 bmin, bmax; uint32_t left, count; } bnode_t; /* count>0: leaf [left,left+count) */
@@ -121,6 +122,7 @@ void orc_params_header_defaults(orc_params_t* p) { /* render_mcpg.hpp:108-166, g
     p->distance_mc_vertex_state_count = 10; p->seed = 0;
     { double d = 25.0; p->draine_g = (float)exp(-2.20679 / (d + 3.91029) - 0.428934); p->draine_a = (float)exp(3.62489 - 8.29288 / (d + 5.52825)); }
     p->gbuffer_hide_sun = 1; p->quirk_lc_max_wo_p = 1; p->quirk_n16_wrap = 0; p->volume_forward_project = 1;
+    p->enable_albedo_mipmap = 1; p->enable_emission_mipmap = 1; /* src/gbuffer/gbuffer.hpp defaults; res/default_config.json:530-531 */
 }
 void orc_params_json_defaults(orc_params_t* p) { /* default_config.json:599-638 */
     orc_params_header_defaults(p);
@@ -156,7 +158,7 @@ static void free_state(orc_ctx* c) {
 void orc_destroy(orc_ctx* c) {
     if (!c) return;
     for (int i = 0; i < MAX_GEOMETRIES; i++) { free(c->geo[i].vtx); free(c->geo[i].prev_vtx); free(c->geo[i].idx); free(c->geo[i].ext); }
-    for (int i = 0; i < MAX_GLTEXTURES; i++) free(c->tex[i].px);
+    for (int i = 0; i < MAX_GLTEXTURES; i++) { free(c->tex[i].px); free(c->tex[i].mip); }
     free(c->tex); free(c->tris); free(c->nodes);
     free_state(c);
     free(c);
@@ -180,13 +182,15 @@ int orc_set_geometry(orc_ctx* c, int slot, const float* vtx, const float* prev_v
     for (uint32_t i = 0; i < n_tri * 3; i++) if (idx[i] >= n_vtx) return -2;
     return 0;
 }
+static void build_mips(const orc_ctx* c, tex_t* t);
 int orc_set_texture(orc_ctx* c, uint32_t texnum, uint32_t w, uint32_t h, const uint8_t* rgba8, uint32_t flags) {
     if (texnum >= MAX_GLTEXTURES) return -1;
     tex_t* t = &c->tex[texnum];
-    free(t->px); t->px = NULL; t->w = t->h = 0;
+    free(t->px); free(t->mip); t->px = NULL; t->mip = NULL; t->w = t->h = 0; t->levels = 1;
     if (!rgba8 || !w || !h) return 0;
     t->px = (uint8_t*)dup_mem(rgba8, (size_t)w * h * 4);
     t->w = w; t->h = h; t->flags = flags;
+    if (flags & ORC_TEX_MIPMAP) build_mips(c, t);
     return 0;
 }
 
@@ -236,6 +240,84 @@ static v4 tex_sample(const orc_ctx* c, uint32_t texnum, float s, float t) {
     r.g = omix(omix(a.g, b.g, fx), omix(d.g, e.g, fx), fy);
     r.b = omix(omix(a.b, b.b, fx), omix(d.b, e.b, fx), fy);
     r.a = omix(omix(a.a, b.a, fx), omix(d.a, e.a, fx), fy);
+    return r;
+}
+
+/* ---- mip chain + textureGrad (first hit only, raytrace.glsl:232-245,299-303) ----------------------
+ * DEFINITION (merian's createTextureFromRGBA8 and the hardware sampler are absent): level k+1 is the 2x2 box
+ * filter of level k evaluated on LINEAR float texels, ((a + b) + (c + d)) * 0.25 with source indices clamped,
+ * level sizes max(1, size >> 1), down to 1x1; no 8-bit requantisation.  LOD as in the Vulkan specification:
+ * rho = max over the two screen axes of the length of (ds * w, dt * h), lambda = log2(rho) clamped to the
+ * chain; lambda <= 0 (or a NaN footprint) takes the magnification path = tex_sample; otherwise bilinear
+ * (min filter LINEAR, quake_node.cpp:697) in the two nearest levels, mixed by frac(lambda). */
+static inline uint32_t mip_dim(uint32_t d, uint32_t k) { uint32_t v = d >> k; return v ? v : 1u; }
+static void build_mips(const orc_ctx* c, tex_t* t) {
+    uint32_t levels = 1; while (mip_dim(t->w, levels - 1) > 1 || mip_dim(t->h, levels - 1) > 1) levels++;
+    if (levels > 16) levels = 16;
+    t->levels = levels;
+    size_t total = 0;
+    for (uint32_t k = 1; k < levels; k++) { t->mip_off[k] = total; total += (size_t)mip_dim(t->w, k) * mip_dim(t->h, k) * 4; }
+    if (!total) return;
+    t->mip = (float*)malloc(total * sizeof(float));
+    /* level 0 decoded exactly as a fetch decodes it */
+    float* prev = (float*)malloc((size_t)t->w * t->h * 4 * sizeof(float));
+    for (uint32_t y = 0; y < t->h; y++) for (uint32_t x = 0; x < t->w; x++) { v4 v = texel(c, t, (int)x, (int)y); float* o = prev + 4 * ((size_t)y * t->w + x); o[0] = v.r; o[1] = v.g; o[2] = v.b; o[3] = v.a; }
+    uint32_t pw = t->w, ph = t->h;
+    for (uint32_t k = 1; k < levels; k++) {
+        uint32_t w = mip_dim(t->w, k), h = mip_dim(t->h, k);
+        float* dst = t->mip + t->mip_off[k];
+        for (uint32_t y = 0; y < h; y++) for (uint32_t x = 0; x < w; x++) {
+            uint32_t x0 = 2 * x < pw ? 2 * x : pw - 1, x1 = 2 * x + 1 < pw ? 2 * x + 1 : pw - 1;
+            uint32_t y0 = 2 * y < ph ? 2 * y : ph - 1, y1 = 2 * y + 1 < ph ? 2 * y + 1 : ph - 1;
+            for (int ch = 0; ch < 4; ch++) {
+                float a = prev[4 * ((size_t)y0 * pw + x0) + ch], b = prev[4 * ((size_t)y0 * pw + x1) + ch];
+                float d = prev[4 * ((size_t)y1 * pw + x0) + ch], e = prev[4 * ((size_t)y1 * pw + x1) + ch];
+                dst[4 * ((size_t)y * w + x) + ch] = ((a + b) + (d + e)) * 0.25f;
+            }
+        }
+        if (k == 1) free(prev);
+        prev = dst; pw = w; ph = h;
+    }
+    if (levels == 1) free(prev);
+}
+static inline v4 mip_texel(const orc_ctx* c, const tex_t* t, uint32_t level, int x, int y) {
+    if (level == 0) return texel(c, t, x, y);
+    const float* p = t->mip + t->mip_off[level] + 4 * ((size_t)y * mip_dim(t->w, level) + (size_t)x);
+    v4 r = {p[0], p[1], p[2], p[3]};
+    return r;
+}
+static v4 tex_bilinear_level(const orc_ctx* c, const tex_t* tx, uint32_t level, float s, float t) {
+    int w = (int)mip_dim(tx->w, level), h = (int)mip_dim(tx->h, level);
+    int x0, x1, y0, y1; float fx, fy;
+    tex_linear_coord(s, (float)w, w, &x0, &x1, &fx);
+    tex_linear_coord(t, (float)h, h, &y0, &y1, &fy);
+    v4 a = mip_texel(c, tx, level, x0, y0), b = mip_texel(c, tx, level, x1, y0), d = mip_texel(c, tx, level, x0, y1), e = mip_texel(c, tx, level, x1, y1);
+    v4 r;
+    r.r = omix(omix(a.r, b.r, fx), omix(d.r, e.r, fx), fy);
+    r.g = omix(omix(a.g, b.g, fx), omix(d.g, e.g, fx), fy);
+    r.b = omix(omix(a.b, b.b, fx), omix(d.b, e.b, fx), fy);
+    r.a = omix(omix(a.a, b.a, fx), omix(d.a, e.a, fx), fy);
+    return r;
+}
+static v4 tex_sample_grad(const orc_ctx* c, uint32_t texnum, float s, float t, float dsdx, float dtdx, float dsdy, float dtdy) {
+    if (texnum > MAX_GLTEXTURES - 1) texnum = MAX_GLTEXTURES - 1;
+    const tex_t* tx = &c->tex[texnum];
+    if (!tx->px || tx->levels <= 1) return tex_sample(c, texnum, s, t);
+    float fw = (float)tx->w, fh = (float)tx->h;
+    float ax = dsdx * fw, ay = dtdx * fh, bx = dsdy * fw, by = dtdy * fh;
+    float rx = sqrtf(ax * ax + ay * ay), ry = sqrtf(bx * bx + by * by);
+    float rho = rx > ry ? rx : ry; /* NaN compares false: a NaN footprint falls through to level 0 below unless ry is the NaN */
+    if (!(rho > 1.0f)) return tex_sample(c, texnum, s, t);
+    float lambda = orc_log2(rho);
+    float top = (float)(tx->levels - 1);
+    if (!(lambda < top)) lambda = top;
+    float fl = floorf(lambda);
+    uint32_t lo = (uint32_t)fl, hi = lo + 1 < tx->levels ? lo + 1 : lo;
+    float f = lambda - fl;
+    v4 c0 = tex_bilinear_level(c, tx, lo, s, t);
+    if (hi == lo || !(f > 0.0f)) return c0;
+    v4 c1 = tex_bilinear_level(c, tx, hi, s, t);
+    v4 r = {omix(c0.r, c1.r, f), omix(c0.g, c1.g, f), omix(c0.b, c1.b, f), omix(c0.a, c1.a, f)};
     return r;
 }
 /* textureGather(tex, st, 3).r : alpha of footprint texel (i0, j1) */
@@ -491,7 +573,9 @@ static inline v3 rd3(const float* p, uint32_t i) { return V3(p[3 * i], p[3 * i +
 
 /* raytrace.glsl:156-311.  throughput / contribution / albedo are float16 in the reference: values
  * are rounded to half at every store. `hit` carries ray origin (pos) and direction (wi) in. */
-static void trace_ray(tls_t* tl, v3* throughput, v3* contribution, hit_t* hit, v3 sun_color) {
+/* `diff`: first hit only (MERIAN_QUAKE_FIRST_HIT, raytrace.glsl:153-156): directions of the camera rays one pixel
+ * to the right and below, diff[0] = r_x, diff[1] = r_y; NULL everywhere else. */
+static void trace_ray(tls_t* tl, v3* throughput, v3* contribution, hit_t* hit, v3 sun_color, const v3* diff) {
     const orc_ctx* c = tl->c;
     rayhit_t rh;
     closest_hit(c, hit->pos, hit->wi, T_MAX, &rh, &tl->ctr);
@@ -530,7 +614,29 @@ static void trace_ray(tls_t* tl, v3* throughput, v3* contribution, hit_t* hit, v
     hit->normal = vnormalize(vcross(du, dv));
     hit->enc_geonormal = orc_encode_normal(hit->normal);
     hit->prev_pos = vadd(vadd(vscale(rd3(g->prev_vtx, i0), b0), vscale(rd3(g->prev_vtx, i1), b1)), vscale(rd3(g->prev_vtx, i2), b2));
-    v4 at = tex_sample(c, e->texnum_alpha & 0xfffu, s, t);
+    /* :232-239 texture-space footprint of the pixel.  DEFINITIONS (merian-shaders ray_diff_* / pseudoinverse are
+     * absent): Igehy transfer of the differential {dO = 0, dD = r_x} over distance t onto the plane of the hit,
+     * dO' = t r - (dot(t r, n) / dot(D, n)) D; pseudoinverse of the 3x2 edge matrix [du dv] by the normal equations;
+     * st_dudv holds the HALF-precision edge differences of the texture coordinates (f16mat2, :208-209). */
+    float gxs = 0.0f, gxt = 0.0f, gys = 0.0f, gyt = 0.0f;
+    const int use_grad = diff && (c->p.enable_albedo_mipmap || c->p.enable_emission_mipmap);
+    if (use_grad) {
+        v3 n = hit->normal, D = hit->wi;
+        float dn = vdot(D, n);
+        float a = vdot(du, du), b = vdot(du, dv), cc = vdot(dv, dv);
+        float det = a * cc - b * b;
+        float d0x = orc_rh(st2s - st0s), d0y = orc_rh(st2t - st0t), d1x = orc_rh(st1s - st0s), d1y = orc_rh(st1t - st0t);
+        for (int k = 0; k < 2; k++) {
+            v3 dO = vscale(diff[k], rh.t);
+            dO = vsub(dO, vscale(D, vdot(dO, n) / dn));
+            float pu = vdot(du, dO), pv = vdot(dv, dO);
+            float ca = (cc * pu - b * pv) / det, cb = (a * pv - b * pu) / det;
+            float gs = d0x * ca + d1x * cb, gt = d0y * ca + d1y * cb;
+            if (k == 0) { gxs = gs; gxt = gt; } else { gys = gs; gyt = gt; }
+        }
+    }
+    v4 at = (use_grad && c->p.enable_albedo_mipmap) ? tex_sample_grad(c, e->texnum_alpha & 0xfffu, s, t, gxs, gxt, gys, gyt)
+                                                     : tex_sample(c, e->texnum_alpha & 0xfffu, s, t);
     v3 albedo_tex = orc_rh3(V3(orc_pow(orc_rh(at.r), 1.0f / 1.2f), orc_pow(orc_rh(at.g), 1.0f / 1.2f), orc_pow(orc_rh(at.b), 1.0f / 1.2f)));
     if (e->n1_brush == 0xffffffffu) { /* :249-274 */
         uint32_t tn_norm = e->n0_gloss_norm >> 16, tn_gloss = e->n0_gloss_norm & 0xffffu;
@@ -567,7 +673,7 @@ static void trace_ray(tls_t* tl, v3* throughput, v3* contribution, hit_t* hit, v
         uint32_t fb = e->texnum_fb_flags & 0xfffu;
         hit->albedo = albedo_tex;
         if (fb > 0 && fb < MAX_GLTEXTURES) {
-            v4 ft = tex_sample(c, fb, s, t);
+            v4 ft = (use_grad && c->p.enable_emission_mipmap) ? tex_sample_grad(c, fb, s, t, gxs, gxt, gys, gyt) : tex_sample(c, fb, s, t);
             v3 em = orc_ldr_to_hdr(orc_rh3(V3(ft.r, ft.g, ft.b)));
             if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) {
                 *contribution = orc_rh3(vadd(*contribution, orc_rh3(vmul(*throughput, em))));
@@ -610,7 +716,8 @@ static void gbuffer_pixel(tls_t* tl, uint32_t px, uint32_t py) {
     h.pos = cam_x(c);
     v3 incident = V3(0, 0, 0), thr = V3(1, 1, 1);
     v3 sun = c->p.gbuffer_hide_sun ? V3(0, 0, 0) : V3(c->p.sun_color[0], c->p.sun_color[1], c->p.sun_color[2]);
-    trace_ray(tl, &thr, &incident, &h, sun);
+    const v3 diff[2] = {r_x, r_y};
+    trace_ray(tl, &thr, &incident, &h, sun, diff);
     uint16_t* oi = c->gb_irr + 4 * idx;
     oi[0] = orc_f2h(incident.x); oi[1] = orc_f2h(incident.y); oi[2] = orc_f2h(incident.z); oi[3] = orc_f2h(1.0f);
     float keep = (incident.x >= 1e-5f || incident.y >= 1e-5f || incident.z >= 1e-5f) ? 0.0f : 1.0f; /* :107 */
@@ -859,7 +966,7 @@ static void mcpg_pixel(tls_t* tl, uint32_t px, uint32_t py) {
             next.wi = wo;
             next.pos = vsub(cur.pos, vscale(cur.wi, 1e-3f)); /* :144 */
             v3 incident = V3(0, 0, 0), throughput = V3(1, 1, 1);
-            trace_ray(tl, &throughput, &incident, &next, sun);
+            trace_ray(tl, &throughput, &incident, &next, sun, NULL);
             v3 lc_incident; /* :149 */
             if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (p->use_light_cache_tail == 0 && p->max_path_length == 2)) lc_incident = incident;
             else lc_incident = orc_rh3(vmul(throughput, light_cache_get(tl, next.pos, next.normal)));
@@ -1089,7 +1196,7 @@ static void volume_pixel(tls_t* tl, uint32_t px, uint32_t py) {
         hit_t next; memset(&next, 0, sizeof next);
         next.wi = wo; next.pos = cur_pos;
         v3 incident = V3(0, 0, 0), throughput = V3(1, 1, 1);
-        trace_ray(tl, &throughput, &incident, &next, sun);
+        trace_ray(tl, &throughput, &incident, &next, sun, NULL);
         if (p->volume_use_light_cache && !(incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f))
             incident = orc_rh3(vmul(throughput, light_cache_get(tl, next.pos, next.normal))); /* :188-192 */
         const float phase = orc_draine_eval(vdot(first_wi, wo), p->draine_g, p->draine_a);
@@ -1190,7 +1297,7 @@ int orc_trace_rays(orc_ctx* c, const float* org, const float* dir, uint32_t n, u
     return 0;
 }
 
-static const int k_arity[ORC_OP_COUNT][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}, {3, 4}, {7, 3}};
+static const int k_arity[ORC_OP_COUNT][2] = {{1, 1}, {1, 1}, {1, 2}, {2, 1}, {1, 1}, {3, 4}, {10, 5}, {6, 4}, {1, 4}, {4, 1}, {3, 3}, {9, 2}, {3, 3}, {11, 5}, {7, 4}, {7, 4}, {3, 4}, {7, 3}, {7, 4}};
 int orc_op_arity(int op, int* n_in, int* n_out) {
     if (op < 0 || op >= ORC_OP_COUNT) return -1;
     *n_in = k_arity[op][0]; *n_out = k_arity[op][1];
@@ -1229,6 +1336,7 @@ int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n) {
             o[2] = orc_sample_normal_box_muller(a[3], a[4], a[5], a[6]); o[3] = orc_sample_normal_pdf(a[3], a[4], o[2]); break; }
         case ORC_OP_SKY_TEX: { orc_uniform_t save = c->u; c->u.sky_rt_bk = f2u(a[3]); c->u.sky_lf_ft = f2u(a[4]); c->u.sky_up_dn = f2u(a[5]); c->u.cl_time = a[6];
             v3 s = get_sky(c, V3(a[0], a[1], a[2]), V3(c->p.sun_color[0], c->p.sun_color[1], c->p.sun_color[2])); c->u = save; o[0] = s.x; o[1] = s.y; o[2] = s.z; break; }
+        case ORC_OP_TEX_GRAD: { v4 x = tex_sample_grad(c, (uint32_t)a[0], a[1], a[2], a[3], a[4], a[5], a[6]); o[0] = x.r; o[1] = x.g; o[2] = x.b; o[3] = x.a; break; }
         case ORC_OP_TEX_SAMPLE: { v4 x = tex_sample(c, (uint32_t)a[0], a[1], a[2]); o[0] = x.r; o[1] = x.g; o[2] = x.b; o[3] = x.a; break; }
         }
     }

@@ -91,6 +91,7 @@ typedef struct {
     int32_t quirk_lc_max_wo_p; /* 1 = keep `max(wo_p, 10)` of mcpg.comp:170 (default) */
     int32_t quirk_n16_wrap;    /* 1 = wrap N*N to 16 bit as GLSL uint16 arithmetic would (mc.glsl:26) */
     int32_t volume_forward_project; /* render_mcpg.hpp:153 */
+    int32_t enable_albedo_mipmap, enable_emission_mipmap; /* g-buffer node, src/gbuffer/gbuffer.cpp:49-50,79-81 */
 } orc_params_t;
 
 void orc_params_header_defaults(orc_params_t* p); /* src/render_mcpg/render_mcpg.hpp:108-166 */
@@ -102,6 +103,7 @@ enum {
 enum {
     ORC_TEX_SRGB = 1,   /* decode sRGB -> linear on fetch (quake_node.hpp:93-95) */
     ORC_TEX_LINEAR = 2, /* bilinear magnification (else nearest) */
+    ORC_TEX_MIPMAP = 4, /* has a mip chain (TEXPREF_MIPMAP, quake_node.cpp:698): used by the first hit's textureGrad */
 };
 
 enum {
@@ -167,7 +169,8 @@ enum {
     ORC_OP_DISTANCE = 15,   /* mu_t tmax xi, gauss mu sigma xi2 (7) -> t, pdf_t, gauss x, gauss pdf (4) */
     ORC_OP_TEX_SAMPLE = 16, /* texnum-as-float s t (3) -> rgba (4): REPEAT addressing, nearest / bilinear, sRGB decode */
     ORC_OP_SKY_TEX = 17,    /* w3, sky_rt_bk sky_lf_ft sky_up_dn (punned u32), cl_time (7) -> rgb (3): textured skies */
-    ORC_OP_COUNT = 18
+    ORC_OP_TEX_GRAD = 18,   /* texnum s t dsdx dtdx dsdy dtdy (7) -> rgba (4): textureGrad with the mip chain */
+    ORC_OP_COUNT = 19
 };
 int orc_math_eval(orc_ctx* c, int op, const float* in, float* out, uint32_t n);
 int orc_op_arity(int op, int* n_in, int* n_out);

@@ -108,6 +108,22 @@ def test_texture_sampling_bit_exact(gpu_ctx):
         bad = (got.view(np.uint32) != ref.view(np.uint32)).any(-1)
         assert bad.sum() == 0, "%s: %d mismatching samples, first %r got %r ref %r" % (scene, bad.sum(), x[np.argmax(bad)], got[np.argmax(bad)], ref[np.argmax(bad)])
         assert (ref[:, :3].std(0) > 0).all()
+        # textureGrad through the mip chain (first-hit albedo / emission, raytrace.glsl:232-245,299-303): footprints
+        # from magnification to far beyond the chain, anisotropic and degenerate ones
+        z = np.empty((n, 7), np.float32)
+        z[:, :3] = x
+        scale = np.exp2(rng.uniform(-12.0, 3.0, (n, 1))).astype(np.float32)
+        z[:, 3:] = rng.normal(size=(n, 4)).astype(np.float32) * scale
+        z[: n // 50, 3:5] = 0.0  # one axis degenerate
+        z[n // 50: n // 25, 3:] = 0.0  # no footprint at all
+        z[n // 25: n // 20, 3] = np.inf
+        ref = o.math_eval(orc.OP_TEX_GRAD, z)
+        got = ctx.math_eval(orc.OP_TEX_GRAD, z, 4)
+        both_nan = np.isnan(got) & np.isnan(ref)
+        bad = ((got.view(np.uint32) != ref.view(np.uint32)) & ~both_nan).any(-1)
+        assert bad.sum() == 0, "%s grad: %d mismatching samples, first %r got %r ref %r" % (scene, bad.sum(), z[np.argmax(bad)], got[np.argmax(bad)], ref[np.argmax(bad)])
+        lod0 = o.math_eval(orc.OP_TEX_SAMPLE, x)
+        assert (np.abs(ref - lod0).max(-1) > 1e-3).mean() > 0.2  # the chain is actually used
         # textured skies (raytrace.glsl:25-65): the scrolling two-layer sky and the six-sided sky box
         u = ctx.synth_camera(90)
         m = 100000
