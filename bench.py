@@ -80,6 +80,10 @@ def cpu_baseline(ctx, scene, seed, props, W, H, warm, timed):
     for f in range(warm, warm + timed):
         o.process(ctx.synth_camera(f), threads=cores)
     dt = time.perf_counter() - t0
+    if overlap and rehearsal:  # rehearsal only: the assembled image must contain this rank's tiles of the last frame
+        import mq_tiles
+        got = mq_tiles.tile_image(image.cpu().numpy().reshape(H, W, 4), rank, world)
+        assert np.array_equal(got, local.cpu().numpy().reshape(-1, 64, 4)), "overlapped exchange lost tiles"
     spp = int(ctx.get_property("spp"))
     val = W * H * spp * timed / dt / 1e6
     o.close()
@@ -111,7 +115,7 @@ def main():
     dist = None
     # Rehearsal switch (tests only): all ranks share GPU 0 and the exchange is staged through gloo,
     # so the N > 1 code path can be exercised on a one-GPU box.  Never set for a measurement.
-    rehearsal = os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") == "1"
+    rehearsal = os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") in ("1", "2")  # "2": rehearse the overlapped exchange too
     if rehearsal:
         local_rank = 0
     if world > 1:
@@ -143,6 +147,11 @@ def main():
     tiles, tile_bytes = ctx.tiles_per_rank()
     tiles_ptr, _ = ctx.map_output(mqhip.OUT_TILES)
     local = gathered = vlocal = vgathered = None
+    side = staging = vstaging = image = vimage = None
+    # The exchange of frame N overlaps the rendering of frame N + 1: tiles are copied to a staging buffer on the
+    # render stream, the RCCL all-gather and the un-tiling into a bench-owned image run on a side stream.
+    # MQ_BENCH_SYNC_EXCHANGE=1 keeps everything on the render stream (and un-tiles into MQ_OUT_IRRADIANCE).
+    overlap = world > 1 and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1" and (not rehearsal or os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") == "2")
     if world > 1:
         local = torch.as_tensor(_DevArray(tiles_ptr, tile_bytes // 4), device="cuda")
         gathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
@@ -150,26 +159,51 @@ def main():
             vptr, _ = ctx.map_output(mqhip.OUT_VOLUME_TILES)
             vlocal = torch.as_tensor(_DevArray(vptr, tile_bytes // 4), device="cuda")
             vgathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
+        if overlap:
+            side = torch.cuda.Stream()
+            staging = torch.empty_like(local)
+            image = torch.zeros(W * H * 4, dtype=torch.float32, device="cuda")
+            if vlocal is not None:
+                vstaging = torch.empty_like(vlocal)
+                vimage = torch.zeros(W * H * 4, dtype=torch.float32, device="cuda")
+
+    def gather_sync(dst, src, untile):
+        if rehearsal:
+            torch.cuda.synchronize()
+            g_cpu = torch.empty(dst.numel(), dtype=torch.float32)
+            dist.all_gather_into_tensor(g_cpu, src.cpu())
+            dst.copy_(g_cpu)
+        else:
+            dist.all_gather_into_tensor(dst, src)  # the exchange step: RCCL over xGMI
+        untile(dst.data_ptr(), stream)
 
     def step(frame):
         ctx.process(ctx.synth_camera(frame), True, stream)
-        if world > 1:
-            if rehearsal:
-                torch.cuda.synchronize()
-                g_cpu = torch.empty(gathered.numel(), dtype=torch.float32)
-                dist.all_gather_into_tensor(g_cpu, local.cpu())
-                gathered.copy_(g_cpu)
-            else:
-                dist.all_gather_into_tensor(gathered, local)  # the one exchange step: RCCL over xGMI
-            ctx.untile(gathered.data_ptr(), stream)
+        if world == 1:
+            return
+        if not overlap:
+            gather_sync(gathered, local, ctx.untile)
             if vlocal is not None:
-                if rehearsal:
-                    g_cpu = torch.empty(vgathered.numel(), dtype=torch.float32)
-                    dist.all_gather_into_tensor(g_cpu, vlocal.cpu())
-                    vgathered.copy_(g_cpu)
+                gather_sync(vgathered, vlocal, ctx.untile_volume)
+            return
+        main = torch.cuda.current_stream()
+        main.wait_stream(side)          # the previous frame's exchange (it ran beside this frame's kernels) is done
+        staging.copy_(local)
+        if vlocal is not None:
+            vstaging.copy_(vlocal)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for dst, src, img in ((gathered, staging, image), (vgathered, vstaging, vimage)):
+                if src is None:
+                    continue
+                if rehearsal:  # one shared GPU: stage the gather through gloo
+                    side.synchronize()
+                    g_cpu = torch.empty(dst.numel(), dtype=torch.float32)
+                    dist.all_gather_into_tensor(g_cpu, src.cpu())
+                    dst.copy_(g_cpu)
                 else:
-                    dist.all_gather_into_tensor(vgathered, vlocal)
-                ctx.untile_volume(vgathered.data_ptr(), stream)
+                    dist.all_gather_into_tensor(dst, src)
+                ctx.untile_to(dst.data_ptr(), img.data_ptr(), side.cuda_stream)
 
     def sync_all():
         if world > 1:
@@ -186,6 +220,10 @@ def main():
         step(frame); frame += 1
     sync_all()
     dt = time.perf_counter() - t0
+    if overlap and rehearsal:  # rehearsal only: the assembled image must contain this rank's tiles of the last frame
+        import mq_tiles
+        got = mq_tiles.tile_image(image.cpu().numpy().reshape(H, W, 4), rank, world)
+        assert np.array_equal(got, local.cpu().numpy().reshape(-1, 64, 4)), "overlapped exchange lost tiles"
     # device time of the render megakernel, averaged over exactly the timed launches (hipEvents
     # recorded on the launch stream inside mq_process)
     n_timed, render_sum, update_sum = ctx.timing_get()
@@ -245,7 +283,7 @@ def main():
            "config": {"workload": "%s(seed=%d) stand-in for ad_sepulcher, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
                                   % (args.scene, args.scene_seed, W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
                       "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world,
-                      "collective": "none" if world == 1 else "%dx RCCL all_gather of %d B/rank per frame" % (2 if args.volume_spp > 0 else 1, tile_bytes)},
+                      "collective": "none" if world == 1 else "%dx RCCL all_gather of %d B/rank per frame%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "")},
            "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, args.scene, args.scene_seed, props, 960, 540, 6, 10)

@@ -202,6 +202,9 @@ int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 int mq_set_partition(mq_ctx* ctx, int rank, int world);
 int mq_tiles_per_rank(const mq_ctx* ctx, uint32_t* tiles, size_t* bytes);
 int mq_untile(mq_ctx* ctx, const void* gathered_dev, void* stream);
+/* the same into a caller-owned W*H RGBA32F device image (an exchange that overlaps the next frame must not write
+ * into MQ_OUT_IRRADIANCE, which the next frame's kernels are filling) */
+int mq_untile_to(mq_ctx* ctx, const void* gathered_dev, void* image_dev, void* stream);
 /* the same for the gathered MQ_OUT_VOLUME_TILES buffers -> MQ_OUT_VOLUME */
 int mq_untile_volume(mq_ctx* ctx, const void* gathered_dev, void* stream);
 

@@ -931,6 +931,15 @@ int mq_untile(mq_ctx* c, const void* gathered_dev, void* stream) {
     return MQ_OK;
 }
 
+int mq_untile_to(mq_ctx* c, const void* gathered_dev, void* image_dev, void* stream) {
+    if (!c || !gathered_dev || !image_dev) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
+    HIPCHK(c, hipSetDevice(c->device));
+    int e = mq_launch_untile(gathered_dev, image_dev, c->W, c->H, c->tiles_x, c->tiles_x * c->tiles_y, (uint32_t)c->world, c->tiles_per_rank, (hipStream_t)stream);
+    if (e) return fail(c, MQ_EHIP, std::string("untile launch: ") + hipGetErrorString((hipError_t)e));
+    return MQ_OK;
+}
 int mq_untile_volume(mq_ctx* c, const void* gathered_dev, void* stream) {
     if (!c || !gathered_dev) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");

@@ -122,6 +122,7 @@ def load_library(path=None):
         "mq_tiles_per_rank": (i32, [P, u32p, C.POINTER(sz)]),
         "mq_untile": (i32, [P, vp, vp]),
         "mq_untile_volume": (i32, [P, vp, vp]),
+        "mq_untile_to": (i32, [P, vp, vp, vp]),
         "mq_trace_rays": (i32, [P, vp, vp, u32, vp, vp, vp]),
         "mq_math_eval": (i32, [P, i32, vp, vp, u32]),
         "mq_synth_scene": (i32, [P, C.c_char_p, u32]),
@@ -350,6 +351,9 @@ class Context:
 
     def untile(self, gathered_dev_ptr, stream=None):
         self._chk(self.lib.mq_untile(self.h, gathered_dev_ptr, stream))
+
+    def untile_to(self, gathered_dev_ptr, image_dev_ptr, stream=None):
+        self._chk(self.lib.mq_untile_to(self.h, gathered_dev_ptr, image_dev_ptr, stream))
 
     def untile_volume(self, gathered_dev_ptr, stream=None):
         self._chk(self.lib.mq_untile_volume(self.h, gathered_dev_ptr, stream))
