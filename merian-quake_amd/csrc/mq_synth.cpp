@@ -202,7 +202,9 @@ void make_textures(mq_ctx* ctx, Rng& rng) {
 
 bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string& err) {
     int G; float q; float outdoor_frac; float sun_k; float mu_t = 0.0f;
-    if (!strcmp(name, "synth_start")) { G = 4; q = 32.0f; outdoor_frac = 0.0f; sun_k = 0.0f; }
+    bool material_zoo = false; // panels of every material class of raytrace.glsl:95-119,198-204,246-311 in every room
+    if (!strcmp(name, "synth_materials")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; mu_t = 1e-3f; material_zoo = true; }
+    else if (!strcmp(name, "synth_start")) { G = 4; q = 32.0f; outdoor_frac = 0.0f; sun_k = 0.0f; }
     else if (!strcmp(name, "synth_tiny")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; }
     else if (!strcmp(name, "synth_tiny_fog")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; mu_t = 2e-3f; }
     else if (!strcmp(name, "synth_start_fog")) { G = 4; q = 32.0f; outdoor_frac = 0.2f; sun_k = 4.0f; mu_t = 2e-3f; }
@@ -294,6 +296,33 @@ bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string
             float sz = 32.0f + 16.0f * rng.range(3);
             float bx = (k & 1) ? x1 - sz - 8 : x0 + 8, by = rng.uni() < 0.5f ? y1 - sz - 8 : y0 + 8;
             gen.box(gen.world, {bx, by, 0}, {bx + sz, by + sz, sz}, 1 + rng.range(16), false, org);
+        }
+        if (material_zoo) { // free-standing double-sided panels, one per material class, off the camera path
+            struct Panel { int flags; int alpha; bool alpha_geo; int kind; }; // kind 0 textured brush, 1 solid particle colours, 2 alias-style (encoded vertex normals)
+            const Panel panels[] = {
+                {MQ_MAT_FLAGS_LAVA, 15, false, 0}, {MQ_MAT_FLAGS_SLIME, 15, false, 0}, {MQ_MAT_FLAGS_TELE, 15, false, 0}, {MQ_MAT_FLAGS_WATER, 15, false, 0},
+                {MQ_MAT_FLAGS_WATERFALL, 15, false, 0}, {MQ_MAT_FLAGS_SPRITE, 15, false, 0}, {MQ_MAT_FLAGS_SOLID, 15, false, 1}, {0, 15, false, 2},
+                {0, 3, true, 0},                      // vertex alpha (3 - 1) / 14 < 0.666: rays pass (raytrace.glsl:108-110)
+                {0, 12, true, 0},                     // vertex alpha (12 - 1) / 14 >= 0.666: rays stop
+                {0, 0, true, 0},                      // alpha from the texture (the grate)
+                {MQ_MAT_FLAGS_WATER, 3, true, 0},     // liquid in the alpha-tested set: always confirmed (flags in [1, 6], :104-106)
+            };
+            const int np = (int)(sizeof panels / sizeof panels[0]);
+            for (int k = 0; k < np; k++) {
+                const Panel& pn = panels[k];
+                float px0 = org.x + 48.0f + 34.0f * k, py = org.y + 112.0f + 36.0f * (k & 1), z0 = 8.0f, z1 = 88.0f, w = 30.0f;
+                mq_ext e; memset(&e, 0, sizeof e);
+                int tex = pn.alpha == 0 ? (int)TEX_GRATE : 1 + (k % 16);
+                e.texnum_alpha = (uint16_t)(tex | ((uint32_t)pn.alpha << 12));
+                e.texnum_fb_flags = (uint16_t)((uint32_t)pn.flags << 12);
+                if (pn.kind == 0) e.n1_brush = 0xffffffffu;
+                else if (pn.kind == 1) { e.n0_gloss_norm = 0x00c08040u + 0x010101u * (uint32_t)k; e.n1_brush = 0x00204080u; } // albedo / emission colour bytes (:275-278)
+                else { e.n0_gloss_norm = 0x12345678u; e.n1_brush = 0x23456789u; e.n2 = 0x3456789au; }                          // encoded vertex normals (unused by the shader, :279-285)
+                float st[8] = {0, 0, 0.5f, 0, 0.5f, 1.25f, 0, 1.25f};
+                Mesh& m = pn.alpha_geo ? gen.alpha : gen.world;
+                m.quad({px0, py, z0}, {px0 + w, py, z0}, {px0 + w, py, z1}, {px0, py, z1}, {0, -1, 0}, st, e);
+                m.quad({px0, py, z0}, {px0 + w, py, z0}, {px0 + w, py, z1}, {px0, py, z1}, {0, 1, 0}, st, e);
+            }
         }
         if (rng.uni() < 0.2f) { // a "moving" box: dynamic slot, prev_vtx offset by its per-frame velocity
             V vel = {2.0f * (rng.uni() - 0.5f), 2.0f * (rng.uni() - 0.5f), 0.0f};

@@ -7,6 +7,8 @@
 
 #define MQ_T_MAX 10000.0f          // res/shader/config.h:11
 #define MQ_ALPHA_THRESHOLD 0.666f  // res/shader/config.h:13
+#define MQ_MAT_FLAGS_LAVA 1
+#define MQ_MAT_FLAGS_SLIME 2
 #define MQ_MAT_FLAGS_TELE 3        // res/shader/config.h:26-35
 #define MQ_MAT_FLAGS_WATER 4
 #define MQ_MAT_FLAGS_SKY 5

@@ -172,7 +172,7 @@ def random_rays(ctx, n, rng):
     return org, d
 
 
-@pytest.mark.parametrize("scene,n", [("synth_tiny", 50000), ("synth_start", 200000)])
+@pytest.mark.parametrize("scene,n", [("synth_tiny", 50000), ("synth_start", 200000), ("synth_materials", 100000)])
 def test_closest_hit_matches_oracle(gpu_ctx, scene, n):
     """CWBVH closest hit == oracle closest hit: identical (slot, prim), t and barycentrics, incl.
     back-face culling and the alpha-tested any-hit geometry (raytrace.glsl:82-119)."""
@@ -216,6 +216,9 @@ def test_oracle_bvh_equals_brute_force(gpu_ctx):
     ("synth_start", 96, 64, {"spp": 2, "max path length": 2, "hide sun": 0}),
     ("synth_start_fog", 320, 200, {"spp": 1}),
     ("synth_sepulcher", 256, 144, {"spp": 1, "max path length": 4}),
+    # every material class (liquid warps, teleporter / waterfall / sprite emission, solid particle colours, alias-style
+    # triangles, vertex alpha below and above the threshold, texture alpha, liquids in the alpha-tested set) in fog
+    ("synth_materials", 224, 160, {"spp": 2, "max path length": 4}),
 ])
 def test_reference_mode_frame_parity(gpu_ctx, scene, W, H, props):
     """Deterministic (unguided) frame: every output of both nodes matches the oracle.
