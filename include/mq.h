@@ -191,6 +191,13 @@ int mq_reset_state(mq_ctx* ctx); /* next process() behaves like iteration 0 */
 /* Profiling builds (-DMQ_PROF) only: shader clocks per kernel code section, summed over all waves
  * since the last reset, followed by 64 histogram bins (rays by loop iterations in the queue kernel, bins of 8);
  * all zero in a product build.  Section ids: tools/prof_sections.py. */
+/* Learning state in the device layout: which 0 = Markov-chain table (64 B per state: w_tgt f32x3, sum_w, w_cos, T, id u32,
+ * N | hash << 16 u32, mv f16x3, padding), 1 = light cache (16 B per cell: hash u32, lock u32, irradiance f16x3, N u16),
+ * 2 = distance Markov chains (16 B: sum_w f32, N u32, m0 f32, m1 f32).
+ * `bytes` must equal the table size.  Writing needs one processed frame (the first frame zeroes the tables).
+ * Test hook, with the property "debug: freeze learning": a guided frame from a given state is deterministic. */
+int mq_debug_state_read(mq_ctx* ctx, int which, void* dst_host, size_t bytes);
+int mq_debug_state_write(mq_ctx* ctx, int which, const void* src_host, size_t bytes);
 #define MQ_PROF_SECTION_COUNT 32
 int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 

@@ -175,6 +175,7 @@ const PropDesc k_props[] = {
     {"hide sun", PT_BOOL, POFF(hide_sun), false, {}},
     {"enable albedo mipmap", PT_BOOL, POFF(enable_albedo_mipmap), false, {}},
     {"enable emission mipmap", PT_BOOL, POFF(enable_emission_mipmap), false, {}},
+    {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
     {"quirk: 16-bit N*N", PT_BOOL, POFF(quirk_n16_wrap), false, {}},
@@ -281,7 +282,7 @@ void props_to_params(mq_ctx* c) {
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
     P.volume_forward_project = q.volume_forward_project;
-    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap;
+    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning;
     P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
     for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
@@ -918,6 +919,34 @@ int mq_debug_section_clocks(mq_ctx* c, uint64_t* out, int n, int reset) {
     HIPCHK(c, hipMemcpy(&d, c->d_counters.p, sizeof d, hipMemcpyDeviceToHost));
     for (int i = 0; i < n && i < MQ_PROF_SECTIONS + 64; i++) out[i] = i < MQ_PROF_SECTIONS ? d.prof[i] : d.ray_hist[i - MQ_PROF_SECTIONS];
     if (reset) HIPCHK(c, hipMemset((char*)c->d_counters.p + offsetof(MqCountersDev, prof), 0, sizeof d.prof + sizeof d.ray_hist));
+    return MQ_OK;
+}
+
+// Learning state in the device layout (MqMCState 64 B / MqLCCell 16 B per entry): lets a test start the GPU
+// from the oracle's learned tables.  Writing needs one processed frame (the first frame zeroes the tables).
+static int state_buf(mq_ctx* c, int which, DevBuf** b) {
+    if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
+    if (which == 0) *b = &c->d_mc; else if (which == 1) *b = &c->d_lc; else if (which == 2) *b = &c->d_dist_mc;
+    else return fail(c, MQ_EINVAL, "state: 0 = Markov chains, 1 = light cache, 2 = distance Markov chains");
+    return MQ_OK;
+}
+int mq_debug_state_read(mq_ctx* c, int which, void* dst, size_t bytes) {
+    if (!c || !dst) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    DevBuf* b = nullptr; int r = state_buf(c, which, &b); if (r) return r;
+    if (bytes != b->bytes) return fail(c, MQ_EINVAL, "state size mismatch");
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost));
+    return MQ_OK;
+}
+int mq_debug_state_write(mq_ctx* c, int which, const void* src, size_t bytes) {
+    if (!c || !src) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    DevBuf* b = nullptr; int r = state_buf(c, which, &b); if (r) return r;
+    if (bytes != b->bytes) return fail(c, MQ_EINVAL, "state size mismatch");
+    if (c->iteration == 0) return fail(c, MQ_ESTATE, "process one frame before writing state (the first frame zeroes it)");
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(b->p, src, bytes, hipMemcpyHostToDevice));
     return MQ_OK;
 }
 

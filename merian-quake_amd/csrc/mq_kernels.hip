@@ -653,6 +653,7 @@ MQ_DEV void light_cache_update(const MqParams& P, const mq_uniform& U, MqLCCell*
     float a = mmax(1.0f / (float)N, MQ_LC_MIN_ALPHA);
     uint32_t o0 = f2h(mmix(cur.x, irr.x, a)), o1 = f2h(mmix(cur.y, irr.y, a)), o2 = f2h(mmix(cur.z, irr.z, a));
     const uint32_t nz = o0 | (o1 << 16), nw = o2 | (N << 16);
+    if (P.freeze_learning) return;
     // One aligned store publishes the cell: 16 bytes when the cell is (re)keyed, else the 8-byte
     // (irradiance, N) payload.  Two lanes racing on one cell lose one of the two updates -- the
     // reference drops contended updates too -- and scattered atomics (about 20 G/s on this chip)
@@ -699,6 +700,7 @@ MQ_DEV void load_chit(const uint32_t* src, Hit& h) { // hit.glsl.h:45-53
 MQ_DEV void enqueue_update(const MqParams& P, const MqFrame& F, uint32_t& rng, uint32_t index, uint32_t id, f3 pos, float w, f3 target, f3 target_mv, f3 normal, Ctr& ctr) {
     const mq_uniform& U = F.u;
     if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, rng, pos, normal, index, h16); }
+    if (P.freeze_learning) return;
     // Cap (mc.glsl:169-184): the returning increment of the slot's counter is this update's arrival
     // rank; ranks >= MQ_MAX_UPDATES are dropped.  The queue position is allocated at the same time
     // (wave-aggregated append to this wave's shard), so the two atomics overlap and only ONE memory
@@ -1228,7 +1230,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
                     if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
                         f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
                         enqueue_update(P, F, p.rng, p.mc_index, p.mc_id, p.cur.pos, mc_f, next.pos, mv, p.cur.normal, ctr);
-                    } else if (P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
+                    } else if (P.mc_fast_recovery && !P.freeze_learning && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
                         F.mc[p.mc_index].sum_w = 0.0f; // mcpg.comp:177
                     }
                 }
@@ -1508,15 +1510,17 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel
                 uint4 gb = *(const uint4*)(F.gbuffer + 4 * pidx);
                 F.volume_depth[pidx] = f2h(v.ds.sum_w > 0.0f ? v.ds.m0 / v.ds.sum_w : __uint_as_float(gb.y));
             }
-            if (xorshift(v.rng) < l / (v.dist_score_sum / (float)P.distance_mc_samples)) // :213
-                F.dist_mc[distance_mc_index(P, F, v.rng, (float)v.px, (float)v.py, grid_max_x)] = make_float4(v.ds.sum_w, __uint_as_float(v.ds.N), v.ds.m0, v.ds.m1);
+            if (xorshift(v.rng) < l / (v.dist_score_sum / (float)P.distance_mc_samples)) { // :213
+                const uint32_t di = distance_mc_index(P, F, v.rng, (float)v.px, (float)v.py, grid_max_x);
+                if (!P.freeze_learning) F.dist_mc[di] = make_float4(v.ds.sum_w, __uint_as_float(v.ds.N), v.ds.m0, v.ds.m1);
+            }
             const float mc_f = luminance((incident * phase) * (1.0f / v.wo_p)); // :218
             if (xorshift(v.rng) < mc_f / (v.score_sum / (float)P.mc_samples)) {
                 float x0 = xorshift(v.rng), x1 = xorshift(v.rng);
                 f3 jn = sample_cos_frame(-first_wi, x0, x1);
                 f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
                 enqueue_update(P, F, v.rng, v.mc_index, v.mc_id, cur_pos, mc_f, next.pos, mv, jn, ctr);
-            } else if (P.mc_fast_recovery && v.mc_index != MQ_NIL && !(mc_f > 1e-3f * v.mc_sum_w) && v.lm_dir_ok) {
+            } else if (P.mc_fast_recovery && !P.freeze_learning && v.mc_index != MQ_NIL && !(mc_f > 1e-3f * v.mc_sum_w) && v.lm_dir_ok) {
                 F.mc[v.mc_index].sum_w = 0.0f; // :228
             }
         }

@@ -117,6 +117,8 @@ def load_library(path=None):
         "mq_enable_counters": (i32, [P, i32]),
         "mq_get_counters": (i32, [P, C.POINTER(Counters)]),
         "mq_reset_state": (i32, [P]),
+        "mq_debug_state_read": (i32, [P, i32, vp, sz]),
+        "mq_debug_state_write": (i32, [P, i32, vp, sz]),
         "mq_debug_section_clocks": (i32, [P, C.POINTER(C.c_uint64), i32, i32]),
         "mq_set_partition": (i32, [P, i32, i32]),
         "mq_tiles_per_rank": (i32, [P, u32p, C.POINTER(sz)]),
@@ -331,6 +333,20 @@ class Context:
         c = Counters()
         self._chk(self.lib.mq_get_counters(self.h, C.byref(c)))
         return c.as_dict()
+
+    MC_DTYPE = np.dtype([("w_tgt", "<f4", 3), ("sum_w", "<f4"), ("w_cos", "<f4"), ("T", "<f4"), ("id", "<u4"), ("n_hash", "<u4"),
+                         ("mv", "<u2", 3), ("pad0", "<u2"), ("pad", "<u4", 6)])
+    LC_DTYPE = np.dtype([("hash", "<u4"), ("lock", "<u4"), ("irr", "<u2", 3), ("N", "<u2")])
+    DIST_DTYPE = np.dtype([("sum_w", "<f4"), ("N", "<u4"), ("m0", "<f4"), ("m1", "<f4")])
+
+    def state_read(self, which, count):
+        a = np.zeros(count, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE)[which])
+        self._chk(self.lib.mq_debug_state_read(self.h, which, a.ctypes.data, a.nbytes))
+        return a
+
+    def state_write(self, which, a):
+        a = np.ascontiguousarray(a, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE)[which])
+        self._chk(self.lib.mq_debug_state_write(self.h, which, a.ctypes.data, a.nbytes))
 
     def section_clocks(self, reset=True):
         """-DMQ_PROF builds: shader clocks per code section (tools/prof_sections.py); zeros otherwise."""

@@ -527,6 +527,12 @@ const void* orc_output(orc_ctx* c, int which, size_t* bytes) {
     }
     return NULL;
 }
+void* orc_debug_state(orc_ctx* c, int which, size_t* count, size_t* entry_bytes) {
+    if (which == 0) { *count = (size_t)c->p.mc_adaptive_buffer_size + c->p.mc_static_buffer_size; *entry_bytes = sizeof(mcstate_t); return c->mc; }
+    if (which == 1) { *count = c->p.lc_buffer_size; *entry_bytes = sizeof(lcvertex_t); return c->lc; }
+    if (which == 2) { *count = c->dist_mc_n; *entry_bytes = sizeof(distmc_t); return c->dist_mc; }
+    *count = 0; *entry_bytes = 0; return NULL;
+}
 void orc_get_counters(orc_ctx* c, orc_counters_t* out, int reset) { if (out) *out = c->ctr; if (reset) memset(&c->ctr, 0, sizeof c->ctr); }
 
 /* ---------------------------------------------------------------- sky + trace_ray */
@@ -817,6 +823,7 @@ static void mc_state_add_sample(tls_t* tl, const mcstate_t* st, v3 pos, float w,
     orc_ctx* c = (orc_ctx*)tl->c;
     uint32_t index = mc_buffer_index;
     if (index == 0xffffffffu) { uint16_t h; mc_adaptive_buffer_index(tl, pos, normal, &index, &h); }
+    if (c->p.freeze_learning) return;
     uint32_t old = __atomic_fetch_add(&c->upd_count[index], 1u, __ATOMIC_RELAXED);
     if (old >= MAX_UPDATES) { __atomic_fetch_sub(&c->upd_count[index], 1u, __ATOMIC_RELAXED); tl->ctr.mc_updates_dropped++; return; }
     uint32_t rec;
@@ -874,6 +881,12 @@ static void light_cache_update(tls_t* tl, v3 pos, v3 normal, v3 irr) {
     lc_address(tl, level, pos, normal, &idx, &chk);
     lcvertex_t* cell = &c->lc[idx];
     tl->ctr.lc_touches++;
+    if (c->p.freeze_learning) { /* every RNG draw of the update, none of its stores */
+        if (c->u.frame == 0u) return; /* frame 0: the lock word (0) equals the frame number, the update is cancelled before any draw */
+        lcvertex_t v = *cell;
+        if (v.hash != chk || h_bad(v.irr[0]) || h_bad(v.irr[1]) || h_bad(v.irr[2])) { v3 ci; uint16_t cn; light_cache_get_level(tl, &ci, &cn, level + 1, pos, normal); }
+        return;
+    }
     uint32_t old = __atomic_exchange_n(&cell->lock, c->u.frame, __ATOMIC_ACQ_REL);
     if (old == c->u.frame) { __atomic_fetch_add(&cell->cancel, 1u, __ATOMIC_RELAXED); return; }
     lcvertex_t v = *cell;
@@ -984,7 +997,7 @@ static void mcpg_pixel(tls_t* tl, uint32_t px, uint32_t py) {
                     if (X(tl) * score_sum < mc_f * (float)p->mc_samples) {
                         v3 mv = orc_rh3(vscale(vsub(next.pos, next.prev_pos), 1.0f / c->u.cam_w[3]));
                         mc_state_add_sample(tl, &mc_state, cur.pos, mc_f, next.pos, mv, cur.normal, mc_buffer_index);
-                    } else if (p->mc_fast_recovery && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur.pos)) {
+                    } else if (p->mc_fast_recovery && !p->freeze_learning && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur.pos)) {
                         c->mc[mc_buffer_index].sum_w = 0.0f; /* :177 */
                     }
                 }
@@ -1209,7 +1222,8 @@ static void volume_pixel(tls_t* tl, uint32_t px, uint32_t py) {
             distance_add_sample(&dstate, t, l); /* :202 */
             if (s == p->volume_spp - 1) c->volume_depth[idx] = orc_f2h(dstate.sum_w > 0.0f ? dstate.m0 / dstate.sum_w : linear_z);
             if (X(tl) < l / (dist_score_sum / (float)p->distance_mc_samples)) { /* :213 */
-                c->dist_mc[distance_mc_index(tl, (float)px, (float)py, grid_max_x)] = dstate;
+                uint32_t di = distance_mc_index(tl, (float)px, (float)py, grid_max_x);
+                if (!p->freeze_learning) c->dist_mc[di] = dstate;
             }
             const float mc_f = orc_luminance(vscale(vscale(incident, phase), 1.0f / wo_p)); /* :218 */
             if (X(tl) < mc_f / (score_sum / (float)p->mc_samples)) {
@@ -1217,7 +1231,7 @@ static void volume_pixel(tls_t* tl, uint32_t px, uint32_t py) {
                 v3 jn = orc_sample_cos_frame(vneg(first_wi), x0, x1);
                 v3 mv = orc_rh3(vscale(vsub(next.pos, next.prev_pos), 1.0f / u->cam_w[3]));
                 mc_state_add_sample(tl, &mc_state, cur_pos, mc_f, next.pos, mv, jn, mc_buffer_index);
-            } else if (p->mc_fast_recovery && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur_pos)) {
+            } else if (p->mc_fast_recovery && !p->freeze_learning && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur_pos)) {
                 c->mc[mc_buffer_index].sum_w = 0.0f;
             }
         }

@@ -92,6 +92,7 @@ typedef struct {
     int32_t quirk_n16_wrap;    /* 1 = wrap N*N to 16 bit as GLSL uint16 arithmetic would (mc.glsl:26) */
     int32_t volume_forward_project; /* render_mcpg.hpp:153 */
     int32_t enable_albedo_mipmap, enable_emission_mipmap; /* g-buffer node, src/gbuffer/gbuffer.cpp:49-50,79-81 */
+    int32_t freeze_learning; /* test hook: learning computations and RNG draws run, the stores to MC / LC / distance state do not */
 } orc_params_t;
 
 void orc_params_header_defaults(orc_params_t* p); /* src/render_mcpg/render_mcpg.hpp:108-166 */
@@ -142,6 +143,11 @@ int orc_connect(orc_ctx* c, uint32_t w, uint32_t h);
 int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads);
 const void* orc_output(orc_ctx* c, int which, size_t* bytes);
 void orc_get_counters(orc_ctx* c, orc_counters_t* out, int reset);
+/* learning state, oracle layout: which 0 = Markov chains (52 B: id u32, 3 unused f32, w_tgt f32x3, sum_w, w_cos, mv f16x3,
+ * 2 B padding, T f32, N u16, hash u16), 1 = light cache (24 B: hash, lock, irr f16x3, N u16, ok u32, cancel u32),
+ * 2 = distance Markov chains (16 B: sum_w f32, N u32, m0 f32, m1 f32).
+ * Returns a pointer into the context (valid until the next orc_connect) and the entry count. */
+void* orc_debug_state(orc_ctx* c, int which, size_t* count, size_t* entry_bytes);
 
 /* closest-hit queries (raytrace.glsl:82-119 semantics: back-face cull, alpha any-hit, tmin 0,
  * tmax 1e4).  out_prim = (slot << 28 | prim) or 0xffffffff on miss. */

@@ -30,7 +30,7 @@ class Params(C.Structure):
                 ("volume_phase_p", C.c_float), ("dir_guide_prior", C.c_float), ("dist_guide_p", C.c_float),
                 ("distance_mc_vertex_state_count", C.c_uint32), ("seed", C.c_uint32), ("gbuffer_hide_sun", C.c_int32),
                 ("quirk_lc_max_wo_p", C.c_int32), ("quirk_n16_wrap", C.c_int32), ("volume_forward_project", C.c_int32),
-                ("enable_albedo_mipmap", C.c_int32), ("enable_emission_mipmap", C.c_int32)]
+                ("enable_albedo_mipmap", C.c_int32), ("enable_emission_mipmap", C.c_int32), ("freeze_learning", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -60,6 +60,8 @@ def lib():
         l.orc_get_counters.argtypes = [P, C.POINTER(Counters), C.c_int]
         l.orc_trace_rays.argtypes = [P, P, P, C.c_uint32, P, P, P]
         l.orc_math_eval.argtypes = [P, C.c_int, P, P, C.c_uint32]
+        l.orc_debug_state.restype = C.c_void_p
+        l.orc_debug_state.argtypes = [P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         l.orc_params_header_defaults.argtypes = [C.POINTER(Params)]
         l.orc_params_json_defaults.argtypes = [C.POINTER(Params)]
         _lib = l
@@ -151,6 +153,19 @@ class Oracle:
         self.l.orc_trace_rays(self.h, _ptr(org), _ptr(direction), n, _ptr(prim), _ptr(t), _ptr(uv))
         return prim, t, uv
 
+    MC_DTYPE = np.dtype({"names": ["id", "unused", "w_tgt", "sum_w", "w_cos", "mv", "T", "N", "hash"],
+                         "formats": ["<u4", ("<f4", 3), ("<f4", 3), "<f4", "<f4", ("<u2", 3), "<f4", "<u2", "<u2"],
+                         "offsets": [0, 4, 16, 28, 32, 36, 44, 48, 50], "itemsize": 52})
+    LC_DTYPE = np.dtype([("hash", "<u4"), ("lock", "<u4"), ("irr", "<u2", 3), ("N", "<u2"), ("ok", "<u4"), ("cancel", "<u4")])
+
+    def state(self, which):
+        """Writable numpy view of the oracle's Markov-chain table (which = 0) or light cache (1)."""
+        n, eb = C.c_size_t(), C.c_size_t()
+        p = self.l.orc_debug_state(self.h, which, C.byref(n), C.byref(eb))
+        dt = (self.MC_DTYPE, self.LC_DTYPE, np.dtype([("sum_w", "<f4"), ("N", "<u4"), ("m0", "<f4"), ("m1", "<f4")]))[which]
+        assert p and eb.value == dt.itemsize, (eb.value, dt.itemsize)
+        return np.frombuffer((C.c_char * (n.value * eb.value)).from_address(p), dtype=dt)
+
     def math_eval(self, op, inp):
         inp = np.ascontiguousarray(inp, np.float32)
         n = inp.shape[0]
@@ -179,6 +194,7 @@ def params_from_ctx(ctx, constants=None):
     p.distance_mc_grid_width = int(g("dist mc grid width")); p.distance_mc_vertex_state_count = int(g("dist mc states per vertex"))
     p.volume_phase_p = g("Phase Prob"); p.dist_guide_p = g("dist guide p"); p.volume_forward_project = int(g("volume forward project"))
     p.enable_albedo_mipmap = int(g("enable albedo mipmap")); p.enable_emission_mipmap = int(g("enable emission mipmap"))
+    p.freeze_learning = int(g("debug: freeze learning"))
     import math
     d = g("particle size")
     import numpy as _np

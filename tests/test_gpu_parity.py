@@ -304,6 +304,95 @@ def test_guided_first_frame_matches_oracle_statistics(gpu_ctx):
     assert l2.max() < 1e-3
 
 
+def _copy_learned_state(ctx, o, with_distance=False):
+    import mqhip
+    omc, olc = o.state(0), o.state(1)
+    gmc = np.zeros(len(omc), mqhip.Context.MC_DTYPE)
+    gmc["w_tgt"] = omc["w_tgt"]; gmc["sum_w"] = omc["sum_w"]; gmc["w_cos"] = omc["w_cos"]; gmc["T"] = omc["T"]; gmc["id"] = omc["id"]
+    gmc["n_hash"] = omc["N"].astype(np.uint32) | (omc["hash"].astype(np.uint32) << 16); gmc["mv"] = omc["mv"]
+    glc = np.zeros(len(olc), mqhip.Context.LC_DTYPE)
+    glc["hash"] = olc["hash"]; glc["irr"] = olc["irr"]; glc["N"] = olc["N"]
+    ctx.state_write(0, gmc); ctx.state_write(1, glc)
+    if with_distance:
+        ctx.state_write(2, o.state(2))
+    return gmc, glc
+
+
+def test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx):
+    """The same for a config-4 style frame: surface guiding + single-scatter volume estimator with its distance and
+    direction Markov chains (volume.comp:34-238), from the oracle's learned state, stores switched off."""
+    import mqhip
+    ctx = gpu_ctx
+    W, H = 112, 72
+    o = make_pair(ctx, "synth_start_fog", 7, {"reference mode": 0, "spp": 1, "max path length": 3, **VOL, "volume forward project": 0}, W, H)  # forward projection would feed the previous frame's learned depth in
+    for f in range(5):
+        o.process(ctx.synth_camera(f), threads=1)
+    for f in range(5):  # the device renders the same frames so that its delay-1 inputs (previous volume depth) exist
+        ctx.process(ctx.synth_camera(f))
+    assert (o.state(2)["N"] > 0).sum() > 50
+    ctx.set_property("debug: freeze learning", 1)
+    o.set_params(orc.params_from_ctx(ctx, ctx.get_constants()))
+    try:
+        # volume-pass updates of a frame are applied by the NEXT frame's update pass (render_mcpg.cpp:261-320): one
+        # frozen frame drains what each side still has queued, then the tables are made equal
+        u = ctx.synth_camera(5)
+        ctx.process(u); o.process(u, threads=8)
+        _copy_learned_state(ctx, o, with_distance=True)
+        u = ctx.synth_camera(6)
+        ctx.process(u); o.process(u, threads=8)
+        for name, a, b in (("irradiance", ctx.irradiance(), o.irradiance()), ("volume", ctx.volume(), o.volume())):
+            bad = (a.view(np.uint32) != b.view(np.uint32)).any(-1)
+            assert not bad.any(), "%s: %d pixels differ, first %r: %r vs %r" % (name, bad.sum(), np.argwhere(bad)[0], a[bad][0], b[bad][0])
+        assert ctx.volume()[..., :3].sum() > 0
+    finally:
+        ctx.set_property("debug: freeze learning", 0)
+
+
+def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx):
+    """The WHOLE guided estimator (K Markov-chain lookups with validation and motion extrapolation, lobe selection,
+    vMF / BSDF sampling, the MIS pdf mixture, light-cache reads, the learning computations and their RNG draws) is
+    deterministic once the learning state is given and its stores are switched off: the oracle learns for a few
+    frames, its tables are copied into the device tables, and the next frame must then be bit-identical."""
+    import mqhip
+    ctx = gpu_ctx
+    W, H = 128, 80
+    props = {"reference mode": 0, "spp": 2, "max path length": 3, **SMALL}
+    o = make_pair(ctx, "synth_start", 11, props, W, H)
+    for f in range(5):  # the oracle learns (sequential frame: deterministic)
+        o.process(ctx.synth_camera(f), threads=1)
+    ctx.process(ctx.synth_camera(0))  # the first device frame zeroes the tables; state can be written after it
+    omc, olc = o.state(0), o.state(1)
+    assert (omc["sum_w"] > 0).sum() > 1000 and (olc["N"] > 0).sum() > 1000  # something was learned
+    gmc = np.zeros(len(omc), mqhip.Context.MC_DTYPE)
+    gmc["w_tgt"] = omc["w_tgt"]; gmc["sum_w"] = omc["sum_w"]; gmc["w_cos"] = omc["w_cos"]; gmc["T"] = omc["T"]; gmc["id"] = omc["id"]
+    gmc["n_hash"] = omc["N"].astype(np.uint32) | (omc["hash"].astype(np.uint32) << 16); gmc["mv"] = omc["mv"]
+    glc = np.zeros(len(olc), mqhip.Context.LC_DTYPE)
+    glc["hash"] = olc["hash"]; glc["irr"] = olc["irr"]; glc["N"] = olc["N"]
+    ctx.state_write(0, gmc); ctx.state_write(1, glc)
+    ctx.set_property("debug: freeze learning", 1)
+    p = orc.params_from_ctx(ctx, ctx.get_constants())
+    assert p.freeze_learning == 1
+    o.set_params(p)
+    ctx.enable_counters(True)
+    try:
+        for f in (5, 6):
+            u = ctx.synth_camera(f)
+            o.counters(reset=True)
+            ctx.process(u); o.process(u, threads=8)
+            img, ref = ctx.irradiance(), o.irradiance()
+            cg, co = ctx.counters(), o.counters()
+            for k in ("rays", "segments", "guided_segments", "mc_state_reads"):
+                assert cg[k] == co[k], (f, k, cg[k], co[k])
+            bad = (img.view(np.uint32) != ref.view(np.uint32)).any(-1)
+            assert not bad.any(), "frame %d: %d pixels differ, first %r: %r vs %r" % (f, bad.sum(), np.argwhere(bad)[0], img[bad][0], ref[bad][0])
+            assert ref[..., :3].sum() > 0
+        # nothing was learned while frozen
+        assert np.array_equal(ctx.state_read(0, len(gmc))["sum_w"], gmc["sum_w"])
+    finally:
+        ctx.enable_counters(False)
+        ctx.set_property("debug: freeze learning", 0)
+
+
 VOL = {"volume spp": 2, "particle size": 7.0, "volume: use LC": 1, "dist guide p": 0.9, "Phase Prob": 0.1}
 
 
