@@ -94,6 +94,7 @@ enum {
     MQ_OUT_VOLUME_DEPTH = 8,  /* "volume_depth" R16F, render_mcpg.cpp:46-47 */
     MQ_OUT_VOLUME_MV = 9,     /* "volume_mv" RG16F, render_mcpg.cpp:48-50 */
     MQ_OUT_VOLUME_TILES = 10, /* this rank's "volume" tiles, tile-major (second multi-GPU exchange buffer, configs with volume spp > 0) */
+    MQ_OUT_DEBUG = 11,        /* "debug" RGBA16F (render_mcpg.cpp:51-52, mcpg.comp:212-277); written when the property "debug output connected" is set */
     MQ_OUT_COUNT
 };
 

@@ -66,6 +66,10 @@ class RendererMarkovChainHIP {
         check(mq_describe(ctx_, width, height, &d));
         width_ = width; height_ = height;
         return {{"irradiance", "R32G32B32A32Sfloat", d.bytes[MQ_OUT_IRRADIANCE]},
+                {"volume", "R32G32B32A32Sfloat", d.bytes[MQ_OUT_VOLUME]},
+                {"volume_depth", "R16Sfloat", d.bytes[MQ_OUT_VOLUME_DEPTH]},
+                {"volume_mv", "R16G16Sfloat", d.bytes[MQ_OUT_VOLUME_MV]},
+                {"debug", "R16G16B16A16Sfloat", d.bytes[MQ_OUT_DEBUG]},
                 {"albedo", "R16G16B16A16Sfloat", d.bytes[MQ_OUT_GB_ALBEDO]},
                 {"gbuffer.irradiance", "R16G16B16A16Sfloat", d.bytes[MQ_OUT_GB_IRRADIANCE]},
                 {"mv", "R16G16Sfloat", d.bytes[MQ_OUT_GB_MV]},
@@ -73,6 +77,7 @@ class RendererMarkovChainHIP {
                 {"hits", "CompressedHit40B", d.bytes[MQ_OUT_HITS]},
                 {"markovchain", "buffer", d.state_bytes_markovchain},
                 {"lightcache", "buffer", d.state_bytes_lightcache},
+                {"volume_distancemc", "buffer", d.state_bytes_volume_distancemc},
                 {"update_buffer", "buffer", d.state_bytes_update_queue}};
     }
     // render_mcpg.cpp:105-115: allocate persistent state, invalidate pipelines

@@ -26,6 +26,7 @@ int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F,
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s);
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s);
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+int mq_launch_debug_view(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_stack_lds_entries();
 int mq_launch_stream_read(const void* src, size_t bytes, uint32_t* sink, int grid, hipStream_t s);
 int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int out[3]);
@@ -68,7 +69,7 @@ struct mq_ctx {
     uint32_t n_local_tiles = 0, tiles_per_rank = 0;
     DevBuf d_out[MQ_OUT_COUNT];
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
-    DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2];
+    DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
     DevBuf d_prev_vdepth, d_dist_mc;
     uint32_t dist_mc_n = 0;
     uint32_t ray_cap = 0;
@@ -175,6 +176,7 @@ const PropDesc k_props[] = {
     {"hide sun", PT_BOOL, POFF(hide_sun), false, {}},
     {"enable albedo mipmap", PT_BOOL, POFF(enable_albedo_mipmap), false, {}},
     {"enable emission mipmap", PT_BOOL, POFF(enable_emission_mipmap), false, {}},
+    {"debug output connected", PT_BOOL, POFF(debug_output_connected), false, {}},
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
@@ -282,7 +284,7 @@ void props_to_params(mq_ctx* c) {
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
     P.volume_forward_project = q.volume_forward_project;
-    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning;
+    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning; P.debug_output_connected = q.debug_output_connected;
     P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
     for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
@@ -296,7 +298,7 @@ void free_frame_state(mq_ctx* c) {
     dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
     dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc);
-    dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
+    dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
 void free_scene_dev(mq_ctx* c) {
@@ -304,7 +306,7 @@ void free_scene_dev(mq_ctx* c) {
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
 }
 
-const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16};
+const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8};
 
 void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     memset(d, 0, sizeof *d);
@@ -666,6 +668,7 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_spill, (size_t)c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
     const size_t slots = (size_t)c->tiles_per_rank * 64;
     if ((r = dev_alloc(c, c->d_paths, slots * 160))) return r;
+    if ((r = dev_alloc(c, c->d_debug_rng, (size_t)c->W * c->H * 4))) return r;
     c->ray_cap = (uint32_t)(2 * slots + 1024); // sharded queues interleave 16 tails: room for shard imbalance
     if ((r = dev_alloc(c, c->d_rays, (size_t)c->ray_cap * 32))) return r;
     if ((r = dev_alloc(c, c->d_ray_hits, (size_t)c->ray_cap * 16))) return r;
@@ -706,6 +709,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.u = *u; F.W = c->W; F.H = c->H; F.tiles_x = c->tiles_x; F.tiles_y = c->tiles_y;
     F.n_local_tiles = c->n_local_tiles; F.rank = (uint32_t)c->rank; F.world = (uint32_t)c->world;
     F.irradiance = (float*)c->d_out[MQ_OUT_IRRADIANCE].p; F.tiles_out = (float*)c->d_out[MQ_OUT_TILES].p; F.volume_tiles_out = (float*)c->d_out[MQ_OUT_VOLUME_TILES].p;
+    F.debug = (uint16_t*)c->d_out[MQ_OUT_DEBUG].p; F.debug_rng = (uint32_t*)c->d_debug_rng.p;
     F.gb_albedo = (uint16_t*)c->d_out[MQ_OUT_GB_ALBEDO].p; F.gb_irr = (uint16_t*)c->d_out[MQ_OUT_GB_IRRADIANCE].p;
     F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
@@ -793,6 +797,10 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         e = mq_launch_bounce(c->scene, c->params, F, r, guided, c->count_enabled, c->grid_frame[2], s);
         if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
         if (r < timed) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s));
+    }
+    if (c->params.debug_output_connected) { // mcpg.comp:212-277: part of the surface pass, i.e. before the update pass
+        e = mq_launch_debug_view(c->params, F, c->grid_blocks, s);
+        if (e) return fail(c, MQ_EHIP, std::string("debug view launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (guided) { // render_mcpg.cpp:261-277
         e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, s);

@@ -70,6 +70,7 @@ struct MqProps {
     bool hide_sun = true;
     bool enable_albedo_mipmap = true;
     bool enable_emission_mipmap = true;
+    bool debug_output_connected = false; // the reference derives this from the graph wiring (render_mcpg.cpp:182-183)
     bool freeze_learning = false; // test hook, not a reference property
     // named quirk switches
     bool quirk_lc_max_wo_p = true;

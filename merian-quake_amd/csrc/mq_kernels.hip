@@ -893,6 +893,7 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                 float4 o4 = make_float4(p.irr.x * inv, p.irr.y * inv, p.irr.z * inv, p.m2 * inv);
                 *(float4*)(F.irradiance + 4 * pidx) = o4;
                 *(float4*)(F.tiles_out + 4 * (size_t)slot) = o4;
+                if (P.debug_output_connected) F.debug_rng[pidx] = p.rng;
                 return false;
             }
         }
@@ -1026,6 +1027,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                     float4 o4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     *(float4*)(F.irradiance + 4 * pidx) = o4;
                     *(float4*)(F.tiles_out + 4 * (size_t)my) = o4;
+                    if (P.debug_output_connected) F.debug_rng[pidx] = p.rng;
                 }
             }
         }
@@ -1638,6 +1640,53 @@ __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// debug views, mcpg.comp:212-277 (grid_idx_closest(p, w) = floor(p / w + 0.5); acos / oklch_to_rgb: mq_device.h)
+// ------------------------------------------------------------------------------------------------
+__global__ void mq_debug_view_kernel(MqParams P, MqFrame F) {
+    const mq_uniform& U = F.u;
+    const uint32_t total = F.n_local_tiles * 64u;
+    for (uint32_t my = blockIdx.x * blockDim.x + threadIdx.x; my < total; my += gridDim.x * blockDim.x) {
+        uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+        uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
+        if (px >= F.W || py >= F.H) continue;
+        const size_t pidx = (size_t)py * F.W + px;
+        Hit h; load_chit(F.hits + 10 * pidx, h);
+        uint32_t rng = F.debug_rng[pidx];
+        const float4 irr4 = *(const float4*)(F.irradiance + 4 * pidx);
+        const f3 irr = F3(irr4.x, irr4.y, irr4.z);
+        f3 out = F3(0, 0, 0);
+        MCS st = {};
+        const int sel = P.debug_output_selector;
+        if (sel == 1 || sel == 2 || sel == 6 || sel == 7 || sel == 8) { // mc_adaptive_load, mc.glsl:98-103
+            uint32_t bi, h16;
+            mc_adaptive_buffer_index(P, U, rng, h.pos, h.normal, bi, h16);
+            st = mc_load(F.mc, bi);
+            mc_finalize_load(U, st, h16, false, h.pos, h.normal);
+        }
+        switch (sel) {
+        case 0: out = light_cache_get(P, U, F.lc, rng, h.pos, h.normal) * 5.0f; break;
+        case 1: out = F3(st.sum_w * 0.1f, st.sum_w * 0.1f, st.sum_w * 0.1f); break;
+        case 2: { f3 d = mc_state_dir(st, h.pos); out = F3((d.x + 1.0f) / 2.0f, (d.y + 1.0f) / 2.0f, (d.z + 1.0f) / 2.0f); break; }
+        case 3: {
+            uint32_t level = grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, cam_pos(U), h.pos);
+            i3 g = grid_idx_interpolate(h.pos, mc_inv_width(P, level), 0.5f);
+            uint32_t seed = hash2_grid(g);
+            float x0 = xorshift(seed), x1 = xorshift(seed);
+            float L = mq_exp(0.001f * -length(h.pos - cam_pos(U))) * (0.0f + x0 * 1.0f) + 0.2f;
+            out = oklch_to_rgb(F3(L, 0.2f, 6.28318548202514648f * x1));
+            break; }
+        case 4: out = irr; break;
+        case 5: out = F3(luminance(irr), irr4.w, 0.0f); break;
+        case 6: { float v = st.sum_w > 0.0f ? 1.0f - mclamp(mq_acos(st.w_cos / st.sum_w) * MQ_INV_PI, 0.0f, 1.0f) : 0.0f; out = F3(v, v, v); break; }
+        case 7: { float v = (float)st.N / (float)MQ_ML_MAX_N; out = F3(v, v, v); break; }
+        case 8: out = F3(h2f(st.mv[0]), h2f(st.mv[1]), h2f(st.mv[2])); break;
+        default: break;
+        }
+        *(uint2*)(F.debug + 4 * pidx) = make_uint2((uint32_t)f2h(out.x) | ((uint32_t)f2h(out.y) << 16), (uint32_t)f2h(out.z) | (0x3c00u << 16));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void mq_clear_kernel(MqFrame F) { // clear.comp:15-23, gbuffer.comp:83-90
@@ -1741,6 +1790,10 @@ int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, 
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
     mq_link_kernel<<<grid, 256, 0, s>>>(F);
     mq_apply_kernel<<<grid, 256, 0, s>>>(P, F);
+    return (int)hipGetLastError();
+}
+int mq_launch_debug_view(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
+    mq_debug_view_kernel<<<grid, 256, 0, s>>>(P, F);
     return (int)hipGetLastError();
 }
 int mq_launch_clear(const MqFrame& F, hipStream_t s) {

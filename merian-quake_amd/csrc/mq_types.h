@@ -144,6 +144,7 @@ struct MqParams {
     int32_t debug_output_selector;
     int32_t volume_forward_project;
     int32_t enable_albedo_mipmap, enable_emission_mipmap; // g-buffer node, gbuffer.cpp:49-50,79-81
+    int32_t debug_output_connected; // DEBUG_OUTPUT_CONNECTED, render_mcpg.cpp:182-183 (selector: debug_output_selector above)
     int32_t freeze_learning; // test hook: every learning computation and RNG draw runs, the stores to MC / LC / distance state do not
     // derived on the host with the same float operations the kernels would use (mq_api.cpp props_to_params)
     float mc_static_inv_width;
@@ -190,6 +191,8 @@ struct MqFrame {
     float* irradiance;     // W*H*4 (full image, linear index) -- written for local tiles only
     float* tiles_out;      // n_local_tiles*64*4
     float* volume_tiles_out; // n_local_tiles*64*4: tile-major copy of `volume`
+    uint16_t* debug;       // W*H*4 half: "debug" image (mcpg.comp:212-277), when connected
+    uint32_t* debug_rng;   // W*H: the pixel's RNG state after its samples, kept for the debug view
     uint16_t* gb_albedo;   // W*H*4 half
     uint16_t* gb_irr;      // W*H*4 half
     uint16_t* gb_mv;       // W*H*2 half

@@ -19,7 +19,7 @@ MQ_MAX_GEOMETRIES = 16
 MQ_GEO_OPAQUE, MQ_GEO_STATIC = 1, 2
 MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
 (OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_VOLUME, OUT_VOLUME_DEPTH,
- OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_COUNT) = range(12)
+ OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_DEBUG, OUT_COUNT) = range(13)
 MQ_ENODEVICE = -2
 
 EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),

@@ -98,6 +98,7 @@ struct orc_ctx {
     float* irradiance; uint16_t* gb_albedo; uint16_t* gb_irr; uint16_t* gb_mv; gbuf_t* gbuffer; chit_t* hits;
     /* volume pass (volume.comp, mc_distance.glsl, volume_forward_project.comp) */
     float* volume; uint16_t* volume_depth; uint16_t* prev_volume_depth; uint16_t* volume_mv;
+    uint16_t* debug; /* RGBA16F */
     distmc_t* dist_mc; uint32_t dist_mc_n;
     uint64_t iteration;
     orc_counters_t ctr;
@@ -150,7 +151,7 @@ orc_ctx* orc_create(const orc_params_t* p) {
 static void free_state(orc_ctx* c) {
     free(c->mc); free(c->lc); free(c->upd_count); free(c->upd_rec); free(c->upd_pool); free(c->upd_touched);
     free(c->irradiance); free(c->gb_albedo); free(c->gb_irr); free(c->gb_mv); free(c->gbuffer); free(c->hits);
-    free(c->volume); free(c->volume_depth); free(c->prev_volume_depth); free(c->volume_mv); free(c->dist_mc);
+    free(c->volume); free(c->volume_depth); free(c->prev_volume_depth); free(c->volume_mv); free(c->dist_mc); free(c->debug); c->debug = NULL;
     c->volume = NULL; c->volume_depth = c->prev_volume_depth = c->volume_mv = NULL; c->dist_mc = NULL;
     c->mc = NULL; c->lc = NULL; c->upd_count = c->upd_rec = NULL; c->upd_pool = NULL; c->upd_touched = NULL;
     c->irradiance = NULL; c->gb_albedo = c->gb_irr = c->gb_mv = NULL; c->gbuffer = NULL; c->hits = NULL;
@@ -504,7 +505,7 @@ int orc_connect(orc_ctx* c, uint32_t w, uint32_t h) {
     c->irradiance = (float*)calloc(px, 16);
     c->gb_albedo = (uint16_t*)calloc(px, 8); c->gb_irr = (uint16_t*)calloc(px, 8); c->gb_mv = (uint16_t*)calloc(px, 4);
     c->gbuffer = (gbuf_t*)calloc(px, sizeof(gbuf_t)); c->hits = (chit_t*)calloc(px, sizeof(chit_t));
-    c->volume = (float*)calloc(px, 16); c->volume_depth = (uint16_t*)calloc(px, 2); c->prev_volume_depth = (uint16_t*)calloc(px, 2); c->volume_mv = (uint16_t*)calloc(px, 4);
+    c->volume = (float*)calloc(px, 16); c->volume_depth = (uint16_t*)calloc(px, 2); c->prev_volume_depth = (uint16_t*)calloc(px, 2); c->volume_mv = (uint16_t*)calloc(px, 4); c->debug = (uint16_t*)calloc(px, 8);
     { uint32_t gw = c->p.distance_mc_grid_width > 0 ? (uint32_t)c->p.distance_mc_grid_width : 25u; /* render_mcpg.cpp:80-82 */
       c->dist_mc_n = (w / gw + 2) * (h / gw + 2) * 10u; c->dist_mc = (distmc_t*)calloc(c->dist_mc_n, sizeof(distmc_t)); }
     c->iteration = 0;
@@ -524,6 +525,7 @@ const void* orc_output(orc_ctx* c, int which, size_t* bytes) {
     case ORC_OUT_VOLUME: if (bytes) *bytes = px * 16; return c->volume;
     case ORC_OUT_VOLUME_DEPTH: if (bytes) *bytes = px * 2; return c->volume_depth;
     case ORC_OUT_VOLUME_MV: if (bytes) *bytes = px * 4; return c->volume_mv;
+    case ORC_OUT_DEBUG: if (bytes) *bytes = px * 8; return c->debug;
     }
     return NULL;
 }
@@ -910,6 +912,45 @@ static void light_cache_update(tls_t* tl, v3 pos, v3 normal, v3 irr) {
 #define MAX_MC_SAMPLES 32
 static inline int finite3(v3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
 
+/* mcpg.comp:212-277: the nine debug views, evaluated with the pixel's RNG state after its samples.
+ * DEFINITIONS: grid_idx_closest(p, w) = floor(p / w + 0.5); oklch_to_rgb / acos / exp as in orc_math.h. */
+static void debug_view(tls_t* tl, size_t idx, v3 irr, float second_moment, const chit_t* fh) {
+    orc_ctx* c = (orc_ctx*)tl->c;
+    const orc_params_t* p = &c->p;
+    hit_t h; decompress_hit(fh, &h);
+    v3 out = V3(0, 0, 0);
+    mcstate_t st; memset(&st, 0, sizeof st);
+    const int sel = p->debug_output_selector;
+    if (sel == 1 || sel == 2 || sel == 6 || sel == 7 || sel == 8) { /* mc_adaptive_load, mc.glsl:98-103 */
+        uint32_t bi; uint16_t hash;
+        mc_adaptive_buffer_index(tl, h.pos, h.normal, &bi, &hash);
+        st = c->mc[bi];
+        mc_finalize_load(c, &st, hash, 0, h.pos, h.normal);
+    }
+    switch (sel) {
+    case 0: out = vscale(light_cache_get(tl, h.pos, h.normal), 5.0f); break;
+    case 1: out = V3(st.sum_w * 0.1f, st.sum_w * 0.1f, st.sum_w * 0.1f); break;
+    case 2: { v3 d = mc_state_dir(&st, h.pos); out = V3((d.x + 1.0f) / 2.0f, (d.y + 1.0f) / 2.0f, (d.z + 1.0f) / 2.0f); break; }
+    case 3: {
+        uint32_t level = grid_level(p->adaptive_grid_type, p->mc_adaptive_grid_steps_per_unit_size, p->mc_adaptive_grid_tan_alpha_half, p->mc_adaptive_grid_min_width, p->mc_adaptive_grid_power, cam_x(c), h.pos);
+        float width = grid_width(p->adaptive_grid_type, p->mc_adaptive_grid_steps_per_unit_size, p->mc_adaptive_grid_min_width, p->mc_adaptive_grid_power, level);
+        i3 g = orc_grid_idx_interpolate(h.pos, width, 0.5f); /* closest cell */
+        uint32_t seed = orc_hash2_grid(g);
+        float x0 = orc_xorshift(&seed), x1 = orc_xorshift(&seed);
+        float L = orc_exp(0.001f * -vlen(vsub(h.pos, cam_x(c)))) * (0.0f + x0 * 1.0f) + 0.2f;
+        out = orc_oklch_to_rgb(V3(L, 0.2f, 6.28318548202514648f * x1));
+        break; }
+    case 4: out = irr; break;
+    case 5: out = V3(orc_luminance(irr), second_moment, 0.0f); break;
+    case 6: { float v = st.sum_w > 0.0f ? 1.0f - oclamp(orc_acos(st.w_cos / st.sum_w) * ORC_INV_PI, 0.0f, 1.0f) : 0.0f; out = V3(v, v, v); break; }
+    case 7: { float v = (float)st.N / (float)ML_MAX_N; out = V3(v, v, v); break; }
+    case 8: out = V3(orc_h2f(st.mv[0]), orc_h2f(st.mv[1]), orc_h2f(st.mv[2])); break;
+    default: break;
+    }
+    uint16_t* d = c->debug + 4 * idx;
+    d[0] = orc_f2h(out.x); d[1] = orc_f2h(out.y); d[2] = orc_f2h(out.z); d[3] = orc_f2h(1.0f);
+}
+
 /* mcpg.comp:39-210 */
 static void mcpg_pixel(tls_t* tl, uint32_t px, uint32_t py) {
     orc_ctx* c = (orc_ctx*)tl->c;
@@ -1012,6 +1053,7 @@ static void mcpg_pixel(tls_t* tl, uint32_t px, uint32_t py) {
     if (p->spp > 0) { float inv = 1.0f / (float)p->spp; irr = vscale(irr, inv); second_moment *= inv; }
     float* o = c->irradiance + 4 * idx;
     o[0] = irr.x; o[1] = irr.y; o[2] = irr.z; o[3] = second_moment;
+    if (p->debug_output_connected) debug_view(tl, idx, irr, second_moment, fh);
 }
 
 /* ---------------------------------------------------------------- update application */

@@ -92,6 +92,7 @@ typedef struct {
     int32_t quirk_n16_wrap;    /* 1 = wrap N*N to 16 bit as GLSL uint16 arithmetic would (mc.glsl:26) */
     int32_t volume_forward_project; /* render_mcpg.hpp:153 */
     int32_t enable_albedo_mipmap, enable_emission_mipmap; /* g-buffer node, src/gbuffer/gbuffer.cpp:49-50,79-81 */
+    int32_t debug_output_connected, debug_output_selector; /* DEBUG_OUTPUT_CONNECTED / _SELECTOR, render_mcpg.cpp:172-173 */
     int32_t freeze_learning; /* test hook: learning computations and RNG draws run, the stores to MC / LC / distance state do not */
 } orc_params_t;
 
@@ -117,6 +118,7 @@ enum {
     ORC_OUT_VOLUME = 6,          /* mcpg "volume" RGBA32F (volume.comp:237) */
     ORC_OUT_VOLUME_DEPTH = 7,    /* mcpg "volume_depth" R16F (volume.comp:211) */
     ORC_OUT_VOLUME_MV = 8,       /* mcpg "volume_mv" RG16F (render_mcpg.cpp:284-311) */
+    ORC_OUT_DEBUG = 9,           /* mcpg "debug" RGBA16F (mcpg.comp:212-277), written when debug_output_connected */
     ORC_OUT_COUNT
 };
 

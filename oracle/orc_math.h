@@ -449,4 +449,25 @@ static inline void orc_camera_pixel(v3 dir, float W, float H, v3 up, v3 fwd, flo
     *py = (ny * 0.5f + 0.5f) * H - 0.5f;
 }
 
+
+/* ---- debug views (mcpg.comp:212-277): definitions for two more absent symbols -------------------------------- */
+/* acos on [-1, 1]: Abramowitz & Stegun 4.4.45 (|error| <= 6.7e-5), mirrored for negative arguments */
+static inline float orc_acos(float x) {
+    float a = fabsf(x); if (!(a < 1.0f)) a = 1.0f;
+    float r = sqrtf(1.0f - a) * (1.5707288f + a * (-0.2121144f + a * (0.0742610f + a * -0.0187293f)));
+    return x < 0.0f ? 3.14159274101257324f - r : r;
+}
+/* OKLCH -> linear sRGB (Ottosson 2020); hue in radians */
+static inline v3 orc_oklch_to_rgb(v3 lch) {
+    float cs, sn; orc_sincos2pi(lch.z * 0.15915493667125701904296875f, &cs, &sn);
+    float a = lch.y * cs, b = lch.y * sn;
+    float l_ = lch.x + 0.3963377774f * a + 0.2158037573f * b;
+    float m_ = lch.x - 0.1055613458f * a - 0.0638541728f * b;
+    float s_ = lch.x - 0.0894841775f * a - 1.2914855480f * b;
+    float l = l_ * l_ * l_, m = m_ * m_ * m_, s3 = s_ * s_ * s_;
+    return V3(4.0767416621f * l - 3.3077115913f * m + 0.2309699292f * s3,
+              -1.2684380046f * l + 2.6097574011f * m - 0.3413193965f * s3,
+              -0.0041960863f * l - 0.7034186147f * m + 1.7076147010f * s3);
+}
+
 #endif

@@ -24,7 +24,12 @@ int main() {
     REQUIRE(node.describe_inputs().size() == 8);
     auto outs = node.describe_outputs(1920, 1080);
     REQUIRE(outs[0].name == "irradiance" && outs[0].bytes == 1920u * 1080u * 16u);
-    REQUIRE(outs[5].name == "hits" && outs[5].bytes == 1920u * 1080u * 40u);
+    auto find = [&](const char* n) -> const mq::ConnectorDesc* { for (auto& o : outs) if (o.name == n) return &o; return nullptr; };
+    REQUIRE(find("hits") && find("hits")->bytes == 1920u * 1080u * 40u);
+    REQUIRE(find("volume") && find("volume")->bytes == 1920u * 1080u * 16u);   // render_mcpg.cpp:44-52: volume, volume_depth, volume_mv, debug
+    REQUIRE(find("volume_depth") && find("volume_depth")->bytes == 1920u * 1080u * 2u);
+    REQUIRE(find("volume_mv") && find("debug") && find("debug")->bytes == 1920u * 1080u * 8u);
+    REQUIRE(find("markovchain") && find("lightcache") && find("volume_distancemc") && find("update_buffer"));
     Loader l;
     l.vals["spp"] = 2; l.vals["BSDF Prob"] = 0.1; l.vals["reference mode"] = 0; l.vals["seed"] = 1234; l.vals["randomize seed"] = 0;
     REQUIRE(node.properties(l) == mq::NONE);          // only pipeline-refresh class changes

@@ -7,7 +7,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "oracle", "libmqoracle.so")
 
-(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_VOLUME, OUT_VOLUME_DEPTH, OUT_VOLUME_MV) = range(9)
+(OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_VOLUME, OUT_VOLUME_DEPTH, OUT_VOLUME_MV,
+ OUT_DEBUG) = range(10)
 (OP_EXP2, OP_LOG2, OP_SINCOS2PI, OP_POW, OP_F2H2F, OP_ENC_DEC_NORMAL, OP_BSDF_SAMPLE, OP_VMF_SAMPLE, OP_XORSHIFT,
  OP_PCG4D16, OP_SKY, OP_HASHGRID, OP_LDR_TO_HDR, OP_CAMERA, OP_DRAINE, OP_DISTANCE, OP_TEX_SAMPLE, OP_SKY_TEX, OP_TEX_GRAD) = range(19)
 OP_ARITY = {0: (1, 1), 1: (1, 1), 2: (1, 2), 3: (2, 1), 4: (1, 1), 5: (3, 4), 6: (10, 5), 7: (6, 4), 8: (1, 4), 9: (4, 1),
@@ -30,7 +31,8 @@ class Params(C.Structure):
                 ("volume_phase_p", C.c_float), ("dir_guide_prior", C.c_float), ("dist_guide_p", C.c_float),
                 ("distance_mc_vertex_state_count", C.c_uint32), ("seed", C.c_uint32), ("gbuffer_hide_sun", C.c_int32),
                 ("quirk_lc_max_wo_p", C.c_int32), ("quirk_n16_wrap", C.c_int32), ("volume_forward_project", C.c_int32),
-                ("enable_albedo_mipmap", C.c_int32), ("enable_emission_mipmap", C.c_int32), ("freeze_learning", C.c_int32)]
+                ("enable_albedo_mipmap", C.c_int32), ("enable_emission_mipmap", C.c_int32),
+                ("debug_output_connected", C.c_int32), ("debug_output_selector", C.c_int32), ("freeze_learning", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -195,6 +197,7 @@ def params_from_ctx(ctx, constants=None):
     p.volume_phase_p = g("Phase Prob"); p.dist_guide_p = g("dist guide p"); p.volume_forward_project = int(g("volume forward project"))
     p.enable_albedo_mipmap = int(g("enable albedo mipmap")); p.enable_emission_mipmap = int(g("enable emission mipmap"))
     p.freeze_learning = int(g("debug: freeze learning"))
+    p.debug_output_connected = int(g("debug output connected")); p.debug_output_selector = int(g("debug output"))
     import math
     d = g("particle size")
     import numpy as _np

@@ -348,6 +348,41 @@ def test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx):
         ctx.set_property("debug: freeze learning", 0)
 
 
+DEBUG_VIEWS = ["light cache", "mc weight", "mc mean direction", "mc grid", "irradiance", "moments", "mc cos", "mc N", "mc motion vectors"]
+
+
+def test_debug_views_match_oracle(gpu_ctx):
+    """The nine debug views of mcpg.comp:212-277 (light cache, learned weight / direction / cosine / N / motion, the
+    adaptive grid in OKLCH colours, irradiance, moments), from the oracle's learned state with stores off: bit-exact."""
+    import mqhip
+    ctx = gpu_ctx
+    W, H = 96, 64
+    o = make_pair(ctx, "synth_start", 11, {"reference mode": 0, "spp": 1, "max path length": 3, "debug output connected": 1}, W, H)
+    for f in range(4):
+        o.process(ctx.synth_camera(f), threads=1)
+    ctx.process(ctx.synth_camera(0))
+    _copy_learned_state(ctx, o)
+    ctx.set_property("debug: freeze learning", 1)
+    try:
+        u = ctx.synth_camera(4)
+        seen = []
+        for i, name in enumerate(DEBUG_VIEWS):
+            ctx.set_property("debug output", name)
+            p = orc.params_from_ctx(ctx, ctx.get_constants())
+            assert p.debug_output_selector == i and p.debug_output_connected == 1
+            o.set_params(p)
+            ctx.process(u); o.process(u, threads=8)
+            a = ctx.read_output(mqhip.OUT_DEBUG).view(np.uint16).reshape(H, W, 4)
+            b = o.output(orc.OUT_DEBUG).view(np.uint16).reshape(H, W, 4)
+            assert np.array_equal(a, b), "view %r: %d pixels differ" % (name, (a != b).any(-1).sum())
+            assert (a[..., 3] == 0x3c00).all()
+            seen.append(len(np.unique(a[..., :3].reshape(-1, 3), axis=0)))
+        assert seen[2] > 100 and seen[3] > 100 and seen[4] > 100 and seen[0] > 8, seen  # the views show structure (mv / N can be flat in a static scene)
+    finally:
+        ctx.set_property("debug: freeze learning", 0)
+        ctx.set_property("debug output connected", 0)
+
+
 def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx):
     """The WHOLE guided estimator (K Markov-chain lookups with validation and motion extrapolation, lobe selection,
     vMF / BSDF sampling, the MIS pdf mixture, light-cache reads, the learning computations and their RNG draws) is
