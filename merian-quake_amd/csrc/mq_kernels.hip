@@ -252,6 +252,7 @@ struct Trav {
     uint32_t oct4;   // octinv in every byte; octinv bit k set: direction component k is >= 0
     uint2 G;
     int sp;
+    int sb;          // stack base: entries [sb, sp) are this lane's (rows below sb were handed to helper lanes, see work sharing)
     RayHit hit;
     uint32_t best_key;
     uint32_t tmask, tbase; // triangles of the last visited node that still have to be tested
@@ -265,7 +266,7 @@ MQ_DEV void trav_init(Trav& t, f3 o, f3 d) { // rays end at MQ_T_MAX (raytrace.g
     t.idz = 1.0f / (fabsf(d.z) > 1e-20f ? d.z : (d.z < 0.0f ? -1e-20f : 1e-20f));
     t.oct4 = ((d.x < 0.0f ? 0u : 1u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 4u)) * 0x01010101u;
     t.G = make_uint2(0u, 0x80000000u);
-    t.sp = 0;
+    t.sp = 0; t.sb = 0;
     t.hit.tri = MQ_NIL; t.hit.t = __uint_as_float(0x7f800000u); t.hit.u = 0.0f; t.hit.v = 0.0f;
     t.best_key = MQ_NIL;
     t.tmask = 0; t.tbase = 0;
@@ -343,7 +344,7 @@ MQ_DEV void trav_tri(const MqSceneDev& sc, Trav& t, Ctr& ctr) {
 // Returns true when the traversal is complete.
 MQ_DEV bool trav_next(Trav& t, uint2* stk, unsigned long long* spill) {
     if (t.G.y > 0x00ffffffu) return false;
-    if (t.sp == 0) return true;
+    if (t.sp == t.sb) return true;
     t.sp--;
     t.G = stk[(t.sp < MQ_STACK_LDS ? t.sp : 0) * 64]; // the common case: one LDS read, no address select
     if (t.sp >= MQ_STACK_LDS) { unsigned long long e = spill[t.sp - MQ_STACK_LDS]; t.G = make_uint2((uint32_t)e, (uint32_t)(e >> 32)); } // deep stacks only
@@ -1054,6 +1055,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 #ifndef MQ_TRI_VOTE
 #define MQ_TRI_VOTE 16u
 #endif
+#ifndef MQ_SHARE
+#define MQ_SHARE 1 // idle lanes adopt subtrees of busy lanes once the queue is exhausted (see the kernel)
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
@@ -1084,6 +1088,19 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
 #endif
     Trav t;
     trav_init(t, F3(0, 0, 0), F3(0, 0, 1));
+#if MQ_SHARE
+    // Work sharing in the drain (queue exhausted, lanes running dry): an idle lane adopts the OLDEST pending stack
+    // entry of a busy lane -- the same ray, another subtree -- traverses it with the ray's current closest hit as
+    // its limit and hands its own closest hit back to the ray's owner lane when done.  The closest hit of a ray is
+    // the minimum over its subtrees by (t, key), so the result is the one the owner alone would have found.
+    // owner: lane that holds the ray and writes its result (-1: this lane is an owner); fin: this lane's subtree is
+    // finished; s_pend[owner lane]: helper lanes of that owner still running.
+    __shared__ uint32_t s_pend[MQ_WAVES][64];
+    uint32_t* const pend = &s_pend[threadIdx.x >> 6][0];
+    pend[lane] = 0u;
+    int owner = -1;
+#endif
+    bool fin = false;
     PSTART(ctr);
     for (;;) {
         unsigned long long idle = __ballot(!busy);
@@ -1125,6 +1142,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
                 q = shard_pos(pool_s, (pool_j << 6) + i); // the lane is busy from here on
                 float4 o = F.rays[q], d = F.rays[(size_t)F.ray_cap + q];
                 trav_init(t, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z));
+                fin = false;
                 if (COUNT) ctr.rays++;
 #ifdef MQ_PROF
                 ray_iters = 0;
@@ -1132,11 +1150,46 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             pool_i += n_idle < avail ? n_idle : avail;
+#if MQ_SHARE
+            if (exhausted && pool_i == pool_len) { // no ray left to fetch: idle lanes help busy ones
+                const unsigned long long idles = __ballot(!busy);
+                const bool can_give = busy && !fin && t.sp > t.sb && t.sb < MQ_STACK_LDS;
+                const unsigned long long givers = __ballot(can_give);
+                if (idles && givers) {
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    const uint32_t g_rank = (uint32_t)__popcll(givers & lt), i_rank = (uint32_t)__popcll(idles & lt);
+                    const uint32_t n_pair = (uint32_t)(__popcll(givers) < __popcll(idles) ? __popcll(givers) : __popcll(idles));
+                    // giver of rank r posts its lane id to lane r; the idle lane of rank r then reads it from lane r
+                    const int posted = __builtin_amdgcn_ds_permute((int)((can_give ? g_rank : 63u) << 2), lane);
+                    const int from = __shfl(posted, (int)(i_rank < n_pair ? i_rank : 0u), 64);
+                    const bool take = !busy && i_rank < n_pair;
+                    const bool give = can_give && g_rank < n_pair;
+                    // every lane reads its partner's registers (lanes that do not take read lane `from` = some giver: harmless)
+                    const float ox = __shfl(t.o.x, from, 64), oy = __shfl(t.o.y, from, 64), oz = __shfl(t.o.z, from, 64);
+                    const float dx = __shfl(t.d.x, from, 64), dy = __shfl(t.d.y, from, 64), dz = __shfl(t.d.z, from, 64);
+                    const float ix = __shfl(t.idx, from, 64), iy = __shfl(t.idy, from, 64), iz = __shfl(t.idz, from, 64);
+                    const uint32_t oc = (uint32_t)__shfl((int)t.oct4, from, 64), fq = (uint32_t)__shfl((int)q, from, 64);
+                    const float ht = __shfl(t.hit.t, from, 64), tl = __shfl(t.tlim, from, 64);
+                    const uint32_t bk = (uint32_t)__shfl((int)t.best_key, from, 64);
+                    const int f_sb = __shfl(t.sb, from, 64), f_owner = __shfl(owner, from, 64);
+                    if (take) {
+                        t.o = F3(ox, oy, oz); t.d = F3(dx, dy, dz); t.idx = ix; t.idy = iy; t.idz = iz; t.oct4 = oc;
+                        t.tlim = tl; t.hit.tri = MQ_NIL; t.hit.t = ht; t.hit.u = 0.0f; t.hit.v = 0.0f; t.best_key = bk; // only hits that beat the ray's current one are kept
+                        t.G = (stk - lane)[f_sb * 64 + from]; // the giver's oldest entry
+                        t.sp = 0; t.sb = 0; t.tmask = 0; t.tbase = 0;
+                        q = fq; fin = false;
+                        owner = f_owner >= 0 ? f_owner : from;
+                        __hip_atomic_fetch_add(&pend[owner], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                    if (give) t.sb++;
+                }
+            }
+#endif
         }
         PLAP(ctr, 26);
         if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
         // node phase: lanes without pending triangles visit one node
-        const bool want_node = busy && t.tmask == 0;
+        const bool want_node = busy && !fin && t.tmask == 0;
 #ifdef MQ_PROF
         { const uint32_t nn = (uint32_t)__popcll(__ballot(want_node)), nb = (uint32_t)__popcll(__ballot(busy)); if (nn) { ctr.prof[12]++; ctr.prof[13] += nn; } ctr.prof[11]++; ctr.prof[30] += nb;
           if (exhausted && pool_i == pool_len) { ctr.prof[22]++; ctr.prof[23] += nb; } }
@@ -1148,8 +1201,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
         const bool has_tri = busy && t.tmask != 0;
         const unsigned long long tv = __ballot(has_tri);
         const uint32_t ntri = (uint32_t)__popcll(tv);
-        const uint32_t nbusy = (uint32_t)__popcll(__ballot(busy));
-        if (ntri >= MQ_TRI_VOTE || ntri == nbusy) {
+        const uint32_t nwork = (uint32_t)__popcll(__ballot(busy && !fin));
+        if (ntri >= MQ_TRI_VOTE || ntri == nwork) {
 #ifdef MQ_PROF
             if (ntri) { ctr.prof[14]++; ctr.prof[15] += ntri; }
 #endif
@@ -1159,14 +1212,32 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
 #ifdef MQ_PROF
         if (busy) ray_iters++;
 #endif
-        if (busy && t.tmask == 0) {
-            if (trav_next(t, stk, spill)) {
-                F.ray_hits[q] = make_uint4(t.hit.tri, __float_as_uint(t.hit.t), __float_as_uint(t.hit.u), __float_as_uint(t.hit.v));
-                q = MQ_NIL;
-#ifdef MQ_PROF
-                atomicAdd(&F.counters->ray_hist[ray_iters / 8u < 63u ? ray_iters / 8u : 63u], 1ull);
-#endif
+        if (busy && !fin && t.tmask == 0) fin = trav_next(t, stk, spill);
+#if MQ_SHARE
+        { // finished helpers hand their closest hit to the owner lane, one at a time (wave-uniform loop)
+            unsigned long long hm = __ballot(busy && fin && owner >= 0);
+            while (hm) {
+                const int l = __ffsll((long long)hm) - 1; hm &= hm - 1ull;
+                const int root = __builtin_amdgcn_readlane(owner, l);
+                const uint32_t h_tri = (uint32_t)__builtin_amdgcn_readlane((int)t.hit.tri, l), h_key = (uint32_t)__builtin_amdgcn_readlane((int)t.best_key, l);
+                const float h_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t.hit.t), l));
+                const float h_u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t.hit.u), l));
+                const float h_v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t.hit.v), l));
+                if (lane == root && h_tri != MQ_NIL && (h_t < t.hit.t || (h_t == t.hit.t && h_key < t.best_key))) {
+                    t.hit.tri = h_tri; t.hit.t = h_t; t.hit.u = h_u; t.hit.v = h_v; t.best_key = h_key; t.tlim = trav_limit(h_t);
+                }
+                if (lane == l) { __hip_atomic_fetch_sub(&pend[root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); q = MQ_NIL; owner = -1; fin = false; }
             }
+        }
+        if (busy && fin && owner < 0 && __hip_atomic_load(&pend[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u) {
+#else
+        if (busy && fin) {
+#endif
+            F.ray_hits[q] = make_uint4(t.hit.tri, __float_as_uint(t.hit.t), __float_as_uint(t.hit.u), __float_as_uint(t.hit.v));
+            q = MQ_NIL; fin = false;
+#ifdef MQ_PROF
+            atomicAdd(&F.counters->ray_hist[ray_iters / 8u < 63u ? ray_iters / 8u : 63u], 1ull);
+#endif
         }
         PLAP(ctr, 29);
     }
