@@ -1055,6 +1055,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 #ifndef MQ_TRI_VOTE
 #define MQ_TRI_VOTE 16u
 #endif
+#ifndef MQ_SHARE_MIN_IDLE
+#define MQ_SHARE_MIN_IDLE 8u // a hand-over round costs ~60 instructions of the whole wave: how many idle lanes make it worth it
+#endif
 #ifndef MQ_SHARE
 #define MQ_SHARE 1 // idle lanes adopt subtrees of busy lanes once the queue is exhausted (see the kernel)
 #endif
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
                 const unsigned long long idles = __ballot(!busy);
                 const bool can_give = busy && !fin && t.sp > t.sb && t.sb < MQ_STACK_LDS;
                 const unsigned long long givers = __ballot(can_give);
-                if (idles && givers) {
+                if ((uint32_t)__popcll(idles) >= MQ_SHARE_MIN_IDLE && givers) {
                     const unsigned long long lt = (1ull << lane) - 1ull;
                     const uint32_t g_rank = (uint32_t)__popcll(givers & lt), i_rank = (uint32_t)__popcll(idles & lt);
                     const uint32_t n_pair = (uint32_t)(__popcll(givers) < __popcll(idles) ? __popcll(givers) : __popcll(idles));
