@@ -1226,8 +1226,10 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
                 const float h_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t.hit.t), l));
                 const float h_u = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t.hit.u), l));
                 const float h_v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t.hit.v), l));
-                if (lane == root && h_tri != MQ_NIL && (h_t < t.hit.t || (h_t == t.hit.t && h_key < t.best_key))) {
-                    t.hit.tri = h_tri; t.hit.t = h_t; t.hit.u = h_u; t.hit.v = h_v; t.best_key = h_key; t.tlim = trav_limit(h_t);
+                // the owner takes the hit if it is closer; the ray's other helpers take it as their new limit
+                if ((lane == root || owner == root) && h_tri != MQ_NIL && (h_t < t.hit.t || (h_t == t.hit.t && h_key < t.best_key))) {
+                    if (lane == root) { t.hit.tri = h_tri; t.hit.u = h_u; t.hit.v = h_v; } else t.hit.tri = MQ_NIL; // a helper's own farther hit is obsolete
+                    t.hit.t = h_t; t.best_key = h_key; t.tlim = trav_limit(h_t);
                 }
                 if (lane == l) { __hip_atomic_fetch_sub(&pend[root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); q = MQ_NIL; owner = -1; fin = false; }
             }
