@@ -199,7 +199,7 @@ int mq_reset_state(mq_ctx* ctx); /* next process() behaves like iteration 0 */
  * Test hook, with the property "debug: freeze learning": a guided frame from a given state is deterministic. */
 int mq_debug_state_read(mq_ctx* ctx, int which, void* dst_host, size_t bytes);
 int mq_debug_state_write(mq_ctx* ctx, int which, const void* src_host, size_t bytes);
-#define MQ_PROF_SECTION_COUNT 32
+#define MQ_PROF_SECTION_COUNT 40
 int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 
 /* ---- multi-GPU framebuffer sharding (no reference counterpart) ----

@@ -881,10 +881,12 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
             }
         }
         if (sample_done) { // mcpg.comp:193-198
+            PLAP(ctr, 32);
             sample_done = false;
             f3 contrib = p.fval * (1.0f / p.pp);
             if (mfinite(contrib.x) && mfinite(contrib.y) && mfinite(contrib.z)) { p.irr = p.irr + contrib; float l = luminance(contrib); p.m2 += l * l; }
             p.smp++;
+            PLAP(ctr, 33);
             if (p.smp < P.spp) {
                 load_chit(F.hits + 10 * pidx, p.cur);
                 p.thr = F3(1, 1, 1); p.fval = F3(0, 0, 0); p.pp = 1.0f; p.seg = 1;
@@ -895,6 +897,7 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                 *(float4*)(F.irradiance + 4 * pidx) = o4;
                 *(float4*)(F.tiles_out + 4 * (size_t)slot) = o4;
                 if (P.debug_output_connected) F.debug_rng[pidx] = p.rng;
+                PLAP(ctr, 34);
                 return false;
             }
         }
@@ -1316,9 +1319,11 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             PLAP(ctr, 21);
             p.thr = p.thr * next.albedo; // :184
             p.cur = next;
+            PLAP(ctr, 35);
             bool need_dir = false, sample_done = false;
             if ((p.thr.x < 1e-7f && p.thr.y < 1e-7f && p.thr.z < 1e-7f) || (p.fval.x > 1e-7f || p.fval.y > 1e-7f || p.fval.z > 1e-7f)) sample_done = true;
             else { p.seg++; if (p.seg < P.max_path_length) need_dir = true; else sample_done = true; }
+            PLAP(ctr, 36);
             cont = advance_path<GUIDED, COUNT>(P, F, p, slot, need_dir, sample_done, lobes, ctr);
         }
         PLAP(ctr, 9);

@@ -172,7 +172,7 @@ struct MqSceneDev {
 // 16-byte distance Markov-chain state, grid.h:48-52
 struct MqDistMC { float sum_w; uint32_t N; float m0, m1; };
 
-#define MQ_PROF_SECTIONS 32
+#define MQ_PROF_SECTIONS 40
 struct MqCountersDev {
     unsigned long long rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels, lc_ok, lc_cancel, q_rays, q_nodes, q_tris, q_paths;

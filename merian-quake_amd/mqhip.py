@@ -350,8 +350,8 @@ class Context:
 
     def section_clocks(self, reset=True):
         """-DMQ_PROF builds: shader clocks per code section (tools/prof_sections.py); zeros otherwise."""
-        a = (C.c_uint64 * 96)()
-        self._chk(self.lib.mq_debug_section_clocks(self.h, a, 96, 1 if reset else 0))
+        a = (C.c_uint64 * 104)()  # 40 sections + 64 histogram bins
+        self._chk(self.lib.mq_debug_section_clocks(self.h, a, 104, 1 if reset else 0))
         return list(a)
 
     def reset_state(self):

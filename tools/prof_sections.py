@@ -13,12 +13,13 @@ import mqhip
 SECTIONS = {
     0: "primary: loop overhead", 1: "primary: traversal", 2: "primary: shade first hit", 3: "primary: g-buffer stores",
     4: "advance: entry", 5: "advance: K state lookups", 6: "advance: sample direction", 7: "advance: pdf mixture",
-    8: "advance: bsdf value", 9: "advance: sample/pixel finish", 10: "append + emit ray/path",
+    8: "advance: bsdf value", 9: "after advance (reconverge)", 10: "append + emit ray/path",
+    35: "bounce: throughput update", 36: "bounce: termination test", 32: "finish: reach the branch", 33: "finish: contribution", 34: "finish: stores",
     16: "bounce: loop overhead", 17: "bounce: load path + hit", 18: "bounce: shade hit", 19: "bounce: light cache get",
     20: "bounce: light cache update", 21: "bounce: enqueue update",
     24: "trace: ballot", 25: "trace: refill", 26: "trace: ray fetch", 27: "trace: node phase", 28: "trace: triangle phase", 29: "trace: pop/writeback",
 }
-GROUPS = {"primary": [0, 1, 2, 3], "shared by primary+bounce": [4, 5, 6, 7, 8, 9, 10], "bounce": [16, 17, 18, 19, 20, 21], "trace": [24, 25, 26, 27, 28, 29]}
+GROUPS = {"primary": [0, 1, 2, 3], "shared by primary+bounce": [35, 36, 4, 5, 6, 7, 8, 32, 33, 34, 9, 10], "bounce": [16, 17, 18, 19, 20, 21], "trace": [24, 25, 26, 27, 28, 29]}
 
 def main():
     ap = argparse.ArgumentParser()
@@ -46,7 +47,7 @@ def main():
               f"triangle phase ran in {100 * t_exec / it:.0f} % with {t_lanes / max(t_exec, 1):.1f} lanes")
         print(f"   drain (queue exhausted, pool empty): {100 * dr_it / it:.0f} % of the iterations with {dr_lanes / max(dr_it, 1):.1f} busy lanes; "
               f"before the drain {(nb - dr_lanes) / max(it - dr_it, 1):.1f} busy lanes")
-    hist = clk[32:96]; clk = clk[:32]
+    hist = clk[40:104]; clk = clk[:40]
     if sum(hist):
         n = float(sum(hist)); acc = 0; marks = {}
         for b, h in enumerate(hist):
