@@ -667,7 +667,7 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     c->grid_blocks = std::max(1, c->cu_count) * 8;
     if ((r = dev_alloc(c, c->d_spill, (size_t)c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
     const size_t slots = (size_t)c->tiles_per_rank * 64;
-    if ((r = dev_alloc(c, c->d_paths, slots * 160))) return r;
+    if ((r = dev_alloc(c, c->d_paths, slots * 112))) return r; // 7 fields of 16 bytes (the volume pass uses 6)
     if ((r = dev_alloc(c, c->d_debug_rng, (size_t)c->W * c->H * 4))) return r;
     c->ray_cap = (uint32_t)(2 * slots + 1024); // sharded queues interleave 16 tails: room for shard imbalance
     if ((r = dev_alloc(c, c->d_rays, (size_t)c->ray_cap * 32))) return r;

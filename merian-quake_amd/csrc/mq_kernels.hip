@@ -742,35 +742,38 @@ struct Path {
 };
 
 // Path records are FIELD-MAJOR: 16-byte field k of slot s sits at paths[k * n_slots + s], so the loads and
-// stores of a wave (consecutive slots) are contiguous instead of 160 bytes apart.
+// stores of a wave (consecutive slots) are contiguous.  A record holds only what a path needs AFTER its ray
+// returns (7 fields = 112 bytes): the previous vertex's position / incoming direction / normal / albedo, the
+// estimator's accumulators and the pre-trace sampling data.  The outgoing direction is read back from the ray
+// buffer and its cosine recomputed (same expression, same bits); the vertex's previous position, geometric
+// normal and roughness, and the sample's f value are dead once the ray is emitted.
+#define MQ_PATH_FIELDS 7
 MQ_DEV void store_path(uint4* dst /* paths + slot */, size_t n, const Path& p) {
-    dst[0 * n] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(p.cur.prev_pos.x));
-    dst[1 * n] = make_uint4(__float_as_uint(p.cur.prev_pos.y), __float_as_uint(p.cur.prev_pos.z), __float_as_uint(p.cur.wi.x), __float_as_uint(p.cur.wi.y));
-    dst[2 * n] = make_uint4(__float_as_uint(p.cur.wi.z), __float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y), __float_as_uint(p.cur.normal.z));
-    dst[3 * n] = make_uint4(p.cur.enc_geonormal, (uint32_t)f2h(p.cur.albedo.x) | ((uint32_t)f2h(p.cur.albedo.y) << 16), (uint32_t)f2h(p.cur.albedo.z) | ((uint32_t)f2h(p.cur.roughness) << 16), p.rng);
-    dst[4 * n] = make_uint4(__float_as_uint(p.thr.x), __float_as_uint(p.thr.y), __float_as_uint(p.thr.z), __float_as_uint(p.pp));
-    dst[5 * n] = make_uint4(__float_as_uint(p.fval.x), __float_as_uint(p.fval.y), __float_as_uint(p.fval.z), __float_as_uint(p.m2));
-    dst[6 * n] = make_uint4(__float_as_uint(p.irr.x), __float_as_uint(p.irr.y), __float_as_uint(p.irr.z), p.px | (p.py << 16));
-    dst[7 * n] = make_uint4(__float_as_uint(p.wo.x), __float_as_uint(p.wo.y), __float_as_uint(p.wo.z), __float_as_uint(p.wo_p));
-    dst[8 * n] = make_uint4(__float_as_uint(p.bsdf), __float_as_uint(p.wodotn), __float_as_uint(p.score_sum), __float_as_uint(p.mc_sum_w));
-    dst[9 * n] = make_uint4(p.mc_index, p.mc_id, (uint32_t)p.seg | ((uint32_t)p.smp << 8) | (p.lm_dir_ok ? 0x10000u : 0u), 0u);
+    dst[0 * n] = make_uint4(__float_as_uint(p.cur.pos.x), __float_as_uint(p.cur.pos.y), __float_as_uint(p.cur.pos.z), __float_as_uint(p.cur.wi.x));
+    dst[1 * n] = make_uint4(__float_as_uint(p.cur.wi.y), __float_as_uint(p.cur.wi.z), __float_as_uint(p.cur.normal.x), __float_as_uint(p.cur.normal.y));
+    dst[2 * n] = make_uint4(__float_as_uint(p.cur.normal.z), (uint32_t)f2h(p.cur.albedo.x) | ((uint32_t)f2h(p.cur.albedo.y) << 16),
+                            (uint32_t)f2h(p.cur.albedo.z) | ((uint32_t)p.seg << 16) | ((uint32_t)p.smp << 21) | (p.lm_dir_ok ? 0x20000000u : 0u), p.rng);
+    dst[3 * n] = make_uint4(__float_as_uint(p.thr.x), __float_as_uint(p.thr.y), __float_as_uint(p.thr.z), __float_as_uint(p.pp));
+    dst[4 * n] = make_uint4(__float_as_uint(p.irr.x), __float_as_uint(p.irr.y), __float_as_uint(p.irr.z), __float_as_uint(p.m2));
+    dst[5 * n] = make_uint4(p.px | (p.py << 16), __float_as_uint(p.wo_p), __float_as_uint(p.bsdf), __float_as_uint(p.score_sum));
+    dst[6 * n] = make_uint4(__float_as_uint(p.mc_sum_w), p.mc_index, p.mc_id, 0u);
 }
-MQ_DEV void load_path(const uint4* src /* paths + slot */, size_t n, Path& p) {
-    uint4 a = src[0], b = src[n], c = src[2 * n], d = src[3 * n], e = src[4 * n], f = src[5 * n], g = src[6 * n], h = src[7 * n], i = src[8 * n], j = src[9 * n];
+MQ_DEV void load_path(const uint4* src /* paths + slot */, size_t n, float4 ray_dir, Path& p) {
+    uint4 a = src[0], b = src[n], c = src[2 * n], d = src[3 * n], e = src[4 * n], f = src[5 * n], g = src[6 * n];
     p.cur.pos = F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-    p.cur.prev_pos = F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
-    p.cur.wi = F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
-    p.cur.normal = F3(__uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
-    p.cur.enc_geonormal = d.x;
-    p.cur.albedo = F3(h2f((uint16_t)(d.y & 0xffffu)), h2f((uint16_t)(d.y >> 16)), h2f((uint16_t)(d.z & 0xffffu)));
-    p.cur.roughness = h2f((uint16_t)(d.z >> 16));
-    p.rng = d.w;
-    p.thr = F3(__uint_as_float(e.x), __uint_as_float(e.y), __uint_as_float(e.z)); p.pp = __uint_as_float(e.w);
-    p.fval = F3(__uint_as_float(f.x), __uint_as_float(f.y), __uint_as_float(f.z)); p.m2 = __uint_as_float(f.w);
-    p.irr = F3(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z)); p.px = g.w & 0xffffu; p.py = g.w >> 16;
-    p.wo = F3(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(h.z)); p.wo_p = __uint_as_float(h.w);
-    p.bsdf = __uint_as_float(i.x); p.wodotn = __uint_as_float(i.y); p.score_sum = __uint_as_float(i.z); p.mc_sum_w = __uint_as_float(i.w);
-    p.mc_index = j.x; p.mc_id = j.y; p.seg = (int)(j.z & 0xffu); p.smp = (int)((j.z >> 8) & 0xffu); p.lm_dir_ok = (j.z & 0x10000u) != 0;
+    p.cur.wi = F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+    p.cur.normal = F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+    p.cur.albedo = F3(h2f((uint16_t)(c.y & 0xffffu)), h2f((uint16_t)(c.y >> 16)), h2f((uint16_t)(c.z & 0xffffu)));
+    p.cur.prev_pos = p.cur.pos; p.cur.enc_geonormal = 0; p.cur.roughness = 0.0f; // not kept: dead after the ray was emitted
+    p.seg = (int)((c.z >> 16) & 0x1fu); p.smp = (int)((c.z >> 21) & 0xffu); p.lm_dir_ok = (c.z & 0x20000000u) != 0;
+    p.rng = c.w;
+    p.thr = F3(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z)); p.pp = __uint_as_float(d.w);
+    p.irr = F3(__uint_as_float(e.x), __uint_as_float(e.y), __uint_as_float(e.z)); p.m2 = __uint_as_float(e.w);
+    p.px = f.x & 0xffffu; p.py = f.x >> 16; p.wo_p = __uint_as_float(f.y); p.bsdf = __uint_as_float(f.z); p.score_sum = __uint_as_float(f.w);
+    p.mc_sum_w = __uint_as_float(g.x); p.mc_index = g.y; p.mc_id = g.z;
+    p.fval = F3(0, 0, 0);
+    p.wo = F3(ray_dir.x, ray_dir.y, ray_dir.z);
+    p.wodotn = dot(p.wo, p.cur.normal); // as computed when the direction was chosen
 }
 
 MQ_DEV void flush_counters(MqCountersDev* g, const Ctr& c) {
@@ -1284,7 +1287,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
         const bool valid = queue_valid(qv, q < n ? q : 0u);
         if (q < n && valid) {
             slot = F.queue_slots[round & 1][q];
-            load_path(F.paths + slot, F.n_slots, p);
+            load_path(F.paths + slot, F.n_slots, F.rays[(size_t)F.ray_cap + q], p);
             uint4 hq = F.ray_hits[q];
             RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
             Hit next; next.wi = p.wo; next.pos = p.cur.pos - p.cur.wi * 1e-3f; next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
