@@ -1097,7 +1097,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
 #endif
     Trav t;
     trav_init(t, F3(0, 0, 0), F3(0, 0, 1));
-#if MQ_SHARE
+    // The counting instantiation runs without work sharing: its node / triangle counters price the algorithm's visits,
+    // not the extra ones of helper lanes (which cull with an older limit).
+    constexpr bool SHARE = MQ_SHARE != 0 && !COUNT;
     // Work sharing in the drain (queue exhausted, lanes running dry): an idle lane adopts the OLDEST pending stack
     // entry of a busy lane -- the same ray, another subtree -- traverses it with the ray's current closest hit as
     // its limit and hands its own closest hit back to the ray's owner lane when done.  The closest hit of a ray is
@@ -1108,7 +1110,6 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     uint32_t* const pend = &s_pend[threadIdx.x >> 6][0];
     pend[lane] = 0u;
     int owner = -1;
-#endif
     bool fin = false;
     PSTART(ctr);
     for (;;) {
@@ -1159,8 +1160,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
             pool_i += n_idle < avail ? n_idle : avail;
-#if MQ_SHARE
-            if (exhausted && pool_i == pool_len) { // no ray left to fetch: idle lanes help busy ones
+            if (SHARE && exhausted && pool_i == pool_len) { // no ray left to fetch: idle lanes help busy ones
                 const unsigned long long idles = __ballot(!busy);
                 const bool can_give = busy && !fin && t.sp > t.sb && t.sb < MQ_STACK_LDS;
                 const unsigned long long givers = __ballot(can_give);
@@ -1193,7 +1193,6 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
                     if (give) t.sb++;
                 }
             }
-#endif
         }
         PLAP(ctr, 26);
         if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
@@ -1222,8 +1221,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
         if (busy) ray_iters++;
 #endif
         if (busy && !fin && t.tmask == 0) fin = trav_next(t, stk, spill);
-#if MQ_SHARE
-        { // finished helpers hand their closest hit to the owner lane, one at a time (wave-uniform loop)
+        if (SHARE) { // finished helpers hand their closest hit to the owner lane, one at a time (wave-uniform loop)
             unsigned long long hm = __ballot(busy && fin && owner >= 0);
             while (hm) {
                 const int l = __ffsll((long long)hm) - 1; hm &= hm - 1ull;
@@ -1240,10 +1238,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
                 if (lane == l) { __hip_atomic_fetch_sub(&pend[root], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); q = MQ_NIL; owner = -1; fin = false; }
             }
         }
-        if (busy && fin && owner < 0 && __hip_atomic_load(&pend[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u) {
-#else
-        if (busy && fin) {
-#endif
+        if (busy && fin && owner < 0 && (!SHARE || __hip_atomic_load(&pend[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u)) {
             F.ray_hits[q] = make_uint4(t.hit.tri, __float_as_uint(t.hit.t), __float_as_uint(t.hit.u), __float_as_uint(t.hit.v));
             q = MQ_NIL; fin = false;
 #ifdef MQ_PROF
