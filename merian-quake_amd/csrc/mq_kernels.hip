@@ -1289,6 +1289,13 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
             PLAP(ctr, 17);
             shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
+#ifdef MQ_EXP_BOUNCE_VALU // experiment: extra independent VALU work per path (is the shading kernel issue bound?)
+            { float z[8]; for (int k = 0; k < 8; k++) z[k] = throughput.x + (float)k; for (int i = 0; i < MQ_EXP_BOUNCE_VALU / 8; i++) for (int k = 0; k < 8; k++) z[k] = __builtin_fmaf(z[k], throughput.y, throughput.z);
+              float zs = 0.0f; for (int k = 0; k < 8; k++) zs += z[k]; if (zs == 123.456f) incident.x += 1.0f; }
+#endif
+#ifdef MQ_EXP_BOUNCE_LOAD // experiment: extra 16-byte gathers per path (is it bound by the L1 gather path?)
+            { uint32_t acc = 0; for (int i = 0; i < MQ_EXP_BOUNCE_LOAD; i++) { uint4 x = ((const uint4*)(sc.tris + ((rhit.tri + 977u * (i + 1)) % sc.n_tris)))[i % 3]; acc ^= x.x; } if (acc == 0x12345678u) incident.x += 1.0f; }
+#endif
             PLAP(ctr, 18);
             f3 lc_incident; // mcpg.comp:149
             if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
