@@ -147,8 +147,15 @@ int mq_scene_set_geometry(mq_ctx* ctx, int slot, const float* vtx, const float* 
 int mq_scene_set_texture(mq_ctx* ctx, uint32_t texnum, uint32_t w, uint32_t h,
                          const uint8_t* rgba8, uint32_t flags);
 /* (re)builds the compressed wide BVH and uploads; stands in for merian's "Acceleration Structure
- * Builder" node fed by tlas_info (res/default_config.json:3-20,400-403). */
+ * Builder" node fed by tlas_info (res/default_config.json:3-20,400-403).  As in the reference
+ * (src/game/quake_node.cpp:847-983: static geometry is built at map load, per-frame geometry every
+ * frame) slots flagged MQ_GEO_STATIC form one tree that is rebuilt and uploaded only when one of them
+ * (or a texture) changed; the other slots form a second tree under the same root that every commit
+ * rebuilds -- a commit after changing only non-static slots rewrites just that part of the device
+ * arrays.  The call waits for frames in flight. */
 int mq_scene_commit(mq_ctx* ctx);
+/* how many commits took the full path and how many only rewrote the per-frame part */
+int mq_scene_commit_counts(const mq_ctx* ctx, uint32_t* full, uint32_t* per_frame);
 /* QuakeRenderInfo::constant + constant_data_update, src/game/quake_node.hpp:62-84 */
 int mq_set_constants(mq_ctx* ctx, const mq_constants* c);
 int mq_get_constants(const mq_ctx* ctx, mq_constants* out);

@@ -58,6 +58,17 @@ struct mq_ctx {
     std::vector<MqTri> tris;
     float sah_cost = 0.0f;
     bool committed = false;
+    // two trees under one root: static slots (MQ_GEO_STATIC) are rebuilt only when one of them changed, the
+    // per-frame slots on every commit (quake_node.cpp:847-983); layout in mq_scene_commit.
+    std::vector<MqNode> s_nodes; std::vector<MqTri> s_tris; // the static tree as built
+    float s_sah = 0.0f;
+    bool static_dirty = true, tex_dirty = true;
+    bool joined = false;               // layout of nodes / the device arrays
+    uint32_t static_root_children = 0; // internal children of the static root (joined layout: the per-frame root follows them)
+    uint32_t dev_static_nodes = 0, dev_static_tris = 0; // static part present in the device arrays (joined layout)
+    bool dev_scene_valid = false;
+    std::vector<MqTexDesc> texdesc;    // of the last full commit: shading records of per-frame triangles need them
+    uint32_t commits_full = 0, commits_dynamic = 0;
     // device scene
     DevBuf d_nodes, d_tris, d_shade, d_texdesc, d_texels;
     DevBuf d_ext[MQ_MAX_GEOMETRIES], d_idx[MQ_MAX_GEOMETRIES], d_prev[MQ_MAX_GEOMETRIES];
@@ -97,15 +108,15 @@ struct mq_ctx {
     mq_ctx() : tex(MQ_MAX_GLTEXTURES) {}
 };
 
-MqHostGeo& mq_ctx_geo(mq_ctx* c, int slot) { return c->geo[slot]; }
-MqHostTex& mq_ctx_tex(mq_ctx* c, uint32_t t) { return c->tex[t]; }
+MqHostGeo& mq_ctx_geo(mq_ctx* c, int slot) { c->static_dirty = true; return c->geo[slot]; }
+MqHostTex& mq_ctx_tex(mq_ctx* c, uint32_t t) { c->tex_dirty = true; return c->tex[t]; }
 mq_constants& mq_ctx_constants(mq_ctx* c) { return c->constants; }
 MqSynthInfo& mq_ctx_synth(mq_ctx* c) { return c->synth; }
 void mq_ctx_clear_scene(mq_ctx* c) {
     for (auto& g : c->geo) g = MqHostGeo();
     for (auto& t : c->tex) t = MqHostTex();
     c->synth = MqSynthInfo();
-    c->committed = false;
+    c->committed = false; c->static_dirty = c->tex_dirty = true;
 }
 
 namespace {
@@ -128,6 +139,13 @@ int dev_alloc(mq_ctx* c, DevBuf& b, size_t bytes) {
 int dev_upload(mq_ctx* c, DevBuf& b, const void* src, size_t bytes) {
     int r = dev_alloc(c, b, bytes);
     if (r) return r;
+    if (bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return MQ_OK;
+}
+
+// buffers rewritten every frame: keep the allocation while it is large enough (b.bytes is then the capacity)
+int dev_update(mq_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    if (!b.p || b.bytes < bytes) { int r = dev_alloc(c, b, bytes + bytes / 2 + 4096); if (r) return r; }
     if (bytes) HIPCHK(c, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return MQ_OK;
 }
@@ -456,6 +474,7 @@ int mq_load_properties_json(mq_ctx* c, const char* json_text, const char* node_n
 int mq_scene_set_geometry(mq_ctx* c, int slot, const float* vtx, const float* prev_vtx, uint32_t n_vtx, const uint32_t* idx, const mq_ext* ext, uint32_t n_tri, uint32_t flags) {
     if (!c || slot < 0 || slot >= MQ_MAX_GEOMETRIES) return fail(c, MQ_EINVAL, "geometry slot out of range");
     MqHostGeo& g = c->geo[slot];
+    if (((g.flags & MQ_GEO_STATIC) && g.n_tri()) || ((flags & MQ_GEO_STATIC) && n_tri)) c->static_dirty = true;
     g = MqHostGeo();
     c->committed = false;
     if (n_tri == 0) return MQ_OK;
@@ -474,7 +493,7 @@ int mq_scene_set_texture(mq_ctx* c, uint32_t texnum, uint32_t w, uint32_t h, con
     if (w > 65535 || h > 65535) return fail(c, MQ_EINVAL, "texture too large");
     MqHostTex& t = c->tex[texnum];
     t = MqHostTex();
-    c->committed = false;
+    c->committed = false; c->tex_dirty = true;
     if (!rgba8 || !w || !h) return MQ_OK;
     t.w = w; t.h = h; t.flags = flags; t.px.assign(rgba8, rgba8 + (size_t)w * h * 4);
     return MQ_OK;
@@ -506,14 +525,12 @@ int mq_scene_stats(const mq_ctx* c, uint64_t* n_tris, uint64_t* n_nodes, uint64_
     return MQ_OK;
 }
 
-int mq_scene_commit(mq_ctx* c) {
-    if (!c) return MQ_EINVAL;
-    std::vector<MqTri> flat;
-    size_t total = 0;
-    for (auto& g : c->geo) total += g.n_tri();
-    flat.reserve(total);
+namespace {
+void flatten_slots(mq_ctx* c, bool want_static, std::vector<MqTri>& flat) {
+    flat.clear();
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) {
         MqHostGeo& g = c->geo[s];
+        if (((g.flags & MQ_GEO_STATIC) != 0) != want_static) continue;
         g.dynamic = g.prev_vtx.size() == g.vtx.size() && !g.vtx.empty() && memcmp(g.prev_vtx.data(), g.vtx.data(), g.vtx.size() * 4) != 0;
         for (uint32_t i = 0; i < g.n_tri(); i++) {
             MqTri t; memset(&t, 0, sizeof t);
@@ -523,28 +540,119 @@ int mq_scene_commit(mq_ctx* c) {
             flat.push_back(t);
         }
     }
-    std::string err;
-    if (!mq_build_cwbvh(flat, c->nodes, c->tris, &c->sah_cost, err)) return fail(c, MQ_EINVAL, "bvh build: " + err);
-    c->committed = true;
-    if (c->device < 0) return MQ_OK; // host-only context: BVH available for inspection, nothing to upload
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
-    free_scene_dev(c);
+}
+
+void shade_records(const mq_ctx* c, const MqTri* tris, size_t n, std::vector<MqShadeRec>& recs) {
+    recs.resize(n);
+    const std::vector<MqTexDesc>& desc = c->texdesc;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t key = tris[i].key;
+        const mq_ext& e = c->geo[key >> 28].ext[key & 0x0fffffffu];
+        MqShadeRec& q = recs[i]; memset(&q, 0, sizeof q);
+        static_assert(sizeof(mq_ext) == 28, "extra data is 7 dwords");
+        memcpy(q.ext, &e, 28);
+        q.albedo = desc[std::min<uint32_t>(e.texnum_alpha & 0xfffu, MQ_MAX_GLTEXTURES - 1)];
+        const uint32_t fb = e.texnum_fb_flags & 0xfffu;
+        if (fb < MQ_MAX_GLTEXTURES) q.fb = desc[fb]; else { q.fb.offset = MQ_NIL; }
+    }
+}
+
+// per-slot arrays the kernels read for triangles with distinct previous positions (raytrace.glsl:226-228)
+int upload_slot_arrays(mq_ctx* c, bool statics) {
     int r;
-    if ((r = dev_upload(c, c->d_nodes, c->nodes.data(), c->nodes.size() * sizeof(MqNode)))) return r;
-    if ((r = dev_upload(c, c->d_tris, c->tris.data(), c->tris.size() * sizeof(MqTri)))) return r;
-    memset(&c->scene, 0, sizeof c->scene);
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) {
         MqHostGeo& g = c->geo[s];
+        if (((g.flags & MQ_GEO_STATIC) != 0) != statics) continue;
+        c->scene.geo[s].ext = nullptr; c->scene.geo[s].idx = nullptr; c->scene.geo[s].prev_vtx = nullptr;
         if (!g.n_tri()) continue;
-        if ((r = dev_upload(c, c->d_ext[s], g.ext.data(), g.ext.size() * sizeof(mq_ext)))) return r;
+        if ((r = dev_update(c, c->d_ext[s], g.ext.data(), g.ext.size() * sizeof(mq_ext)))) return r;
         c->scene.geo[s].ext = (const mq_ext*)c->d_ext[s].p;
         if (g.dynamic) {
-            if ((r = dev_upload(c, c->d_idx[s], g.idx.data(), g.idx.size() * 4))) return r;
-            if ((r = dev_upload(c, c->d_prev[s], g.prev_vtx.data(), g.prev_vtx.size() * 4))) return r;
+            if ((r = dev_update(c, c->d_idx[s], g.idx.data(), g.idx.size() * 4))) return r;
+            if ((r = dev_update(c, c->d_prev[s], g.prev_vtx.data(), g.prev_vtx.size() * 4))) return r;
             c->scene.geo[s].idx = (const uint32_t*)c->d_idx[s].p; c->scene.geo[s].prev_vtx = (const float*)c->d_prev[s].p;
         }
     }
+    return MQ_OK;
+}
+} // namespace
+
+int mq_scene_commit(mq_ctx* c) {
+    if (!c) return MQ_EINVAL;
+    std::string err;
+    std::vector<MqTri> flat;
+    const bool static_rebuilt = c->static_dirty;
+    if (c->static_dirty) {
+        flatten_slots(c, true, flat);
+        if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, &c->s_sah, err, 7)) return fail(c, MQ_EINVAL, "bvh build: " + err); // slot 7 of the root stays free for the per-frame tree
+        c->static_dirty = false;
+    }
+    std::vector<MqNode> d_nodes; std::vector<MqTri> d_tris; float d_sah = 0.0f;
+    flatten_slots(c, false, flat);
+    if (!mq_build_cwbvh(flat, d_nodes, d_tris, &d_sah, err)) return fail(c, MQ_EINVAL, "bvh build: " + err);
+    const size_t ns = c->s_nodes.size(), nd = d_nodes.size(), ts = c->s_tris.size(), td = d_tris.size();
+    const bool joined = ns != 0 && nd != 0;
+    // joined layout: [root, the static root's internal children (ki of them), the per-frame root, the other static
+    // nodes, the other per-frame nodes]; triangles of the static tree, then of the per-frame tree.  What lies behind
+    // the static part can be rewritten in place when the static part did not move.
+    const bool in_place = joined && c->joined && !static_rebuilt && c->nodes.size() >= ns + 1 && c->tris.size() >= ts;
+    if (!joined) {
+        c->nodes = ns ? c->s_nodes : d_nodes; c->tris = ns ? c->s_tris : d_tris;
+    } else {
+        MqNode root; uint32_t rank[8] = {}, ki = 0;
+        if (!mq_merge_root(c->s_nodes[0], d_nodes[0], root, rank, &ki)) return fail(c, MQ_EINVAL, "bvh build: static root is full");
+        if (!in_place) {
+            c->nodes.assign(ns + 1, MqNode());
+            for (size_t i = 1; i < ns; i++) {
+                MqNode n = c->s_nodes[i]; n.child_base += 1; // only the root has children among [1, ki]
+                c->nodes[i <= ki ? 1 + rank[i - 1] : i + 1] = n;
+            }
+            c->tris = c->s_tris;
+        }
+        c->static_root_children = ki;
+        c->nodes.resize(ns + nd); c->tris.resize(ts + td);
+        c->nodes[0] = root;
+        for (size_t j = 0; j < nd; j++) {
+            MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ts;
+            c->nodes[j == 0 ? 1 + ki : ns + j] = n;
+        }
+        std::copy(d_tris.begin(), d_tris.end(), c->tris.begin() + (ptrdiff_t)ts);
+    }
+    c->joined = joined;
+    c->sah_cost = c->s_sah + d_sah;
+    c->committed = true;
+    if (c->device < 0) { c->tex_dirty = false; return MQ_OK; } // host-only context: BVH available for inspection, nothing to upload
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    int r;
+    const bool partial = in_place && !c->tex_dirty && c->dev_scene_valid && c->dev_static_nodes == ns && c->dev_static_tris == ts
+        && c->d_nodes.bytes >= c->nodes.size() * sizeof(MqNode) && c->d_tris.bytes >= c->tris.size() * sizeof(MqTri) && c->d_shade.bytes >= c->tris.size() * sizeof(MqShadeRec);
+    if (partial) { // per-frame geometry only: root pair, the per-frame tree, its triangles and shading records
+        std::vector<MqShadeRec> recs;
+        shade_records(c, c->tris.data() + ts, td, recs);
+        const uint32_t ki = c->static_root_children;
+        HIPCHK(c, hipMemcpy(c->d_nodes.p, c->nodes.data(), sizeof(MqNode), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy((MqNode*)c->d_nodes.p + (1 + ki), c->nodes.data() + (1 + ki), sizeof(MqNode), hipMemcpyHostToDevice));
+        if (nd > 1) HIPCHK(c, hipMemcpy((MqNode*)c->d_nodes.p + (ns + 1), c->nodes.data() + (ns + 1), (nd - 1) * sizeof(MqNode), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy((MqTri*)c->d_tris.p + ts, c->tris.data() + ts, td * sizeof(MqTri), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy((MqShadeRec*)c->d_shade.p + ts, recs.data(), td * sizeof(MqShadeRec), hipMemcpyHostToDevice));
+        if ((r = upload_slot_arrays(c, false))) return r;
+        c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
+        c->commits_dynamic++;
+        return MQ_OK;
+    }
+    c->dev_scene_valid = false;
+    free_scene_dev(c);
+    memset(&c->scene, 0, sizeof c->scene);
+    // room for the per-frame part to grow without another full upload
+    const size_t slack_tris = joined ? td + 16384 : 0, slack_nodes = joined ? nd + 8192 : 0;
+    if ((r = dev_alloc(c, c->d_nodes, (c->nodes.size() + slack_nodes) * sizeof(MqNode)))) return r;
+    if ((r = dev_alloc(c, c->d_tris, (c->tris.size() + slack_tris) * sizeof(MqTri)))) return r;
+    if ((r = dev_alloc(c, c->d_shade, (c->tris.size() + slack_tris) * sizeof(MqShadeRec)))) return r;
+    if (!c->nodes.empty()) HIPCHK(c, hipMemcpy(c->d_nodes.p, c->nodes.data(), c->nodes.size() * sizeof(MqNode), hipMemcpyHostToDevice));
+    if (!c->tris.empty()) HIPCHK(c, hipMemcpy(c->d_tris.p, c->tris.data(), c->tris.size() * sizeof(MqTri), hipMemcpyHostToDevice));
+    if ((r = upload_slot_arrays(c, true))) return r;
+    if ((r = upload_slot_arrays(c, false))) return r;
     // Texel pool: linear RGBA32F.  Level 0 decoded once (sRGB through the 256-entry table, quake_node.hpp:93-95,
     // everything else x / 255: the values a per-fetch decode gives); MQ_TEX_MIPMAP textures are followed by their
     // mip chain, level k+1 = 2x2 box filter of level k on the float texels, ((a + b) + (c + d)) * 0.25 with clamped
@@ -590,24 +698,25 @@ int mq_scene_commit(mq_ctx* c) {
         }
     }
     if ((r = dev_upload(c, c->d_texdesc, desc.data(), desc.size() * sizeof(MqTexDesc)))) return r;
+    c->texdesc = desc;
     { // shading records in BVH triangle order
-        std::vector<MqShadeRec> recs(c->tris.size());
-        for (size_t i = 0; i < c->tris.size(); i++) {
-            const uint32_t key = c->tris[i].key;
-            const mq_ext& e = c->geo[key >> 28].ext[key & 0x0fffffffu];
-            MqShadeRec& q = recs[i]; memset(&q, 0, sizeof q);
-            static_assert(sizeof(mq_ext) == 28, "extra data is 7 dwords");
-            memcpy(q.ext, &e, 28);
-            q.albedo = desc[std::min<uint32_t>(e.texnum_alpha & 0xfffu, MQ_MAX_GLTEXTURES - 1)];
-            const uint32_t fb = e.texnum_fb_flags & 0xfffu;
-            if (fb < MQ_MAX_GLTEXTURES) q.fb = desc[fb]; else { q.fb.offset = MQ_NIL; }
-        }
-        if ((r = dev_upload(c, c->d_shade, recs.data(), recs.size() * sizeof(MqShadeRec)))) return r;
+        std::vector<MqShadeRec> recs;
+        shade_records(c, c->tris.data(), c->tris.size(), recs);
+        if (!recs.empty()) HIPCHK(c, hipMemcpy(c->d_shade.p, recs.data(), recs.size() * sizeof(MqShadeRec), hipMemcpyHostToDevice));
     }
     if ((r = dev_upload(c, c->d_texels, lin.data(), lin.size() * 4))) return r;
     c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p; c->scene.shade = (const MqShadeRec*)c->d_shade.p;
     c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const float4*)c->d_texels.p;
     c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
+    c->tex_dirty = false; c->dev_scene_valid = true;
+    c->dev_static_nodes = joined ? (uint32_t)ns : 0; c->dev_static_tris = joined ? (uint32_t)ts : 0;
+    c->commits_full++;
+    return MQ_OK;
+}
+
+int mq_scene_commit_counts(const mq_ctx* c, uint32_t* full, uint32_t* per_frame) {
+    if (!c) return MQ_EINVAL;
+    if (full) *full = c->commits_full; if (per_frame) *per_frame = c->commits_dynamic;
     return MQ_OK;
 }
 

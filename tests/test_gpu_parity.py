@@ -245,6 +245,65 @@ def test_reference_mode_frame_parity(gpu_ctx, scene, W, H, props):
         assert ref[..., :3].sum() > 0
 
 
+def _boxes(centres, half):
+    """Axis-aligned boxes as triangle soup, front faces outward under the reference's normal convention
+    (normalize(cross(v2 - v0, v1 - v0)), raytrace.glsl:221)."""
+    corners = np.array([[x, y, z] for z in (-1, 1) for y in (-1, 1) for x in (-1, 1)], np.float32) * half
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    vtx, idx = [], []
+    for c in centres:
+        base = len(vtx)
+        vtx.extend((corners + np.asarray(c, np.float32)).tolist())
+        for q in quads:
+            for tri in ((q[0], q[1], q[2]), (q[0], q[2], q[3])):
+                v0, v1, v2 = (corners[i] for i in tri)
+                n = np.cross(v2 - v0, v1 - v0)
+                if np.dot(n, (v0 + v1 + v2) / 3) < 0:  # make the geometric normal point away from the box centre
+                    tri = (tri[0], tri[2], tri[1])
+                idx.append([base + i for i in tri])
+    return np.array(vtx, np.float32), np.array(idx, np.uint32)
+
+
+def test_per_frame_geometry_update_parity(gpu_ctx):
+    """Per-frame geometry (quake_node.cpp:896-983: entities are re-submitted with their previous positions every
+    frame): a non-static slot is replaced and committed before every frame.  Only the per-frame tree is rebuilt and
+    uploaded, the frames stay bit-identical to the oracle (which rebuilds everything), and the motion vectors see
+    the previous positions."""
+    import mqhip
+    ctx = gpu_ctx
+    W, H = 160, 96
+    o = make_pair(ctx, "synth_start", 11, {"reference mode": 1, "spp": 1}, W, H)
+    ext0 = ctx.get_geometry(0)["ext"][:1]
+    full0, part0 = ctx.commit_counts()
+    vel = np.array([3.0, 2.0, 1.0], np.float32)
+    moved = False
+    for frame in range(4):
+        u = ctx.synth_camera(frame)
+        cam, fwd = np.array(u.cam_x[:3], np.float32), np.array(u.cam_w[:3], np.float32)
+        n_boxes = 3 + frame  # the triangle count changes from frame to frame as entities come and go
+        centres = [cam + fwd * (60.0 + 25.0 * k) + np.array([8.0 * k - 12.0, 0, -6.0], np.float32) for k in range(n_boxes)]
+        base, idx = _boxes(centres, 6.0)
+        vtx = base + vel * frame
+        prev = base + vel * (frame - 1) if frame else vtx
+        ext = np.repeat(ext0, len(idx))
+        for side in (ctx, o):
+            side.set_geometry(5, vtx, prev, idx, ext, mqhip.MQ_GEO_OPAQUE if side is ctx else 1)
+        ctx.commit(); o.commit(1)
+        ctx.process(u); o.process(u, threads=8)
+        img, ref = ctx.irradiance(), o.irradiance()
+        bad = (img.view(np.uint32) != ref.view(np.uint32)).any(-1)
+        assert not bad.any(), "frame %d: %d pixels not bit-identical" % (frame, bad.sum())
+        for which_g, which_o in ((mqhip.OUT_HITS, orc.OUT_HITS), (mqhip.OUT_GB_MV, orc.OUT_GB_MV), (mqhip.OUT_GBUFFER, orc.OUT_GBUFFER)):
+            a, b = ctx.read_output(which_g), o.output(which_o)
+            assert np.array_equal(a, b), "output %d differs in %d bytes (frame %d)" % (which_g, (a != b).sum(), frame)
+        if frame:
+            moved = moved or bool((ctx.read_output(mqhip.OUT_GB_MV) != 0).any())
+    assert moved, "no pixel saw the moving geometry"
+    full1, part1 = ctx.commit_counts()
+    assert part1 - part0 >= 3 and full1 - full0 <= 1, "per-frame commits took the full path: %r" % ((full1 - full0, part1 - part0),)
+    ctx.set_geometry(5, np.zeros((0, 3), np.float32), None, np.zeros((0, 3), np.uint32), np.zeros(0, mqhip.EXT_DTYPE), 0)
+
+
 def test_clear_pass(gpu_ctx):
     """render == false clears the outputs (clear.comp:15-23)."""
     ctx = gpu_ctx

@@ -144,21 +144,14 @@ def _decode_children(node):
     return lo, hi
 
 
-def test_cwbvh_invariants(mq):
-    ctx = mq.Context(-1)
-    ctx.synth_scene("synth_tiny", 2)
-    ctx.commit()
-    nodes, tris = ctx.get_bvh()
-    total = sum(len(ctx.get_geometry(s)["idx"]) for s in range(3) if ctx.get_geometry(s) is not None)
-    assert len(tris) == total
-    assert len(np.unique(tris["key"])) == total  # every triangle exactly once
-    seen_nodes = np.zeros(len(nodes), bool)
-    seen_tris = np.zeros(len(tris), bool)
-    stack = [(0, None, None)]
+def _walk_bvh(nodes, tris, root=0):
+    """Checks the structural invariants below `root`; returns the sets of nodes and triangles reached."""
+    seen_nodes, seen_tris = set(), set()
+    stack = [(root, None, None)]
     while stack:
         ni, plo, phi = stack.pop()
-        assert not seen_nodes[ni]
-        seen_nodes[ni] = True
+        assert ni not in seen_nodes
+        seen_nodes.add(ni)
         node = nodes[ni]
         lo, hi = _decode_children(node)
         child = int(node["child_base"])
@@ -168,8 +161,9 @@ def test_cwbvh_invariants(mq):
                 assert node["qlo"][0][s] > node["qhi"][0][s]  # empty slots can never be hit
                 continue
             clo, chi = lo[:, s], hi[:, s]
-            if plo is not None:  # child box inside the parent's decoded box
-                assert (clo >= plo - 1e-3).all() and (chi <= phi + 1e-3).all()
+            if plo is not None:  # child box inside the parent's decoded box, up to one step of this node's own (finer) grid
+                tol = (node["e"].astype(np.uint32) << 23).view(np.float32) + 1e-3
+                assert (clo >= plo - tol).all() and (chi <= phi + tol).all()
             if (m & 0x18) == 0x18:  # internal: low 5 bits = 24 + slot, imask bit set, children contiguous in slot order
                 assert (m & 31) == 24 + s and (m >> 5) == 1 and (int(node["imask"]) >> s) & 1
                 stack.append((child, clo, chi)); child += 1
@@ -177,13 +171,60 @@ def test_cwbvh_invariants(mq):
                 cnt = {1: 1, 3: 2, 7: 3}[m >> 5]
                 first = int(node["tri_base"]) + (m & 31)
                 for t in range(first, first + cnt):
-                    assert not seen_tris[t]
-                    seen_tris[t] = True
+                    assert t not in seen_tris
+                    seen_tris.add(t)
                     v = tris[t]["v"]
                     assert (v.min(0) >= clo).all() and (v.max(0) <= chi).all()  # conservative quantised boxes
-    assert seen_nodes.all() and seen_tris.all()
+    return seen_nodes, seen_tris
+
+
+def test_cwbvh_invariants(mq):
+    ctx = mq.Context(-1)
+    ctx.synth_scene("synth_tiny", 2)
+    ctx.commit()
+    nodes, tris = ctx.get_bvh()
+    total = sum(len(ctx.get_geometry(s)["idx"]) for s in range(3) if ctx.get_geometry(s) is not None)
+    assert len(tris) == total
+    assert len(np.unique(tris["key"])) == total  # every triangle exactly once
+    seen_nodes, seen_tris = _walk_bvh(nodes, tris)
+    assert len(seen_nodes) == len(nodes) and len(seen_tris) == len(tris)
     st = ctx.scene_stats()
     assert st["bvh_bytes"] == len(nodes) * 80 + len(tris) * 48
+
+
+def test_static_and_per_frame_trees_share_one_root(mq):
+    """Static slots and per-frame slots are two trees under one root (quake_node.cpp:847-983): the per-frame root is the
+    child in slot 7 of the static root.  Replacing a per-frame slot leaves the static part of the arrays untouched."""
+    ctx = mq.Context(-1)
+    ctx.synth_scene("synth_tiny", 2)
+    ctx.commit()
+    n_static = len(ctx.get_bvh()[1])
+    ext0 = ctx.get_geometry(0)["ext"][:1]
+    snapshots = []
+    for step, n_tri in enumerate((5, 40, 3)):
+        rng = np.random.default_rng(step)
+        vtx = (rng.random((3 * n_tri, 3), dtype=np.float32) * 200 - 100).astype(np.float32)
+        idx = np.arange(3 * n_tri, dtype=np.uint32).reshape(-1, 3)
+        ctx.set_geometry(4, vtx, vtx + 1.0, idx, np.repeat(ext0, n_tri), mq.MQ_GEO_OPAQUE)
+        ctx.commit()
+        nodes, tris = ctx.get_bvh()
+        assert len(tris) == n_static + n_tri
+        root = nodes[0]
+        assert int(root["meta"][7]) == 32 + 31 and int(root["imask"]) & 0x80 and int(root["child_base"]) == 1
+        per_frame_root = 1 + bin(int(root["imask"]) & 0x7f).count("1")  # after the static root's internal children
+        seen_nodes, seen_tris = _walk_bvh(nodes, tris)
+        assert len(seen_nodes) == len(nodes) and len(seen_tris) == len(tris)
+        d_nodes, d_tris = _walk_bvh(nodes, tris, per_frame_root)
+        s_nodes = seen_nodes - d_nodes - {0}
+        assert d_tris == set(range(n_static, n_static + n_tri))
+        assert ((tris["key"][n_static:] >> 28) == 4).all() and (tris["flags"][n_static:] & 2).all()  # distinct previous positions
+        assert max(s_nodes) < min(d_nodes - {per_frame_root}, default=len(nodes))
+        snapshots.append((nodes[sorted(s_nodes)].tobytes(), tris[:n_static].tobytes()))
+    assert all(sn == snapshots[0] for sn in snapshots)
+    ctx.set_geometry(4, np.zeros((0, 3), np.float32), None, np.zeros((0, 3), np.uint32), np.zeros(0, mq.EXT_DTYPE), 0)
+    ctx.commit()
+    nodes, tris = ctx.get_bvh()
+    assert len(tris) == n_static and len(_walk_bvh(nodes, tris)[0]) == len(nodes)
 
 
 def _write_bsp(path, bsp2):
