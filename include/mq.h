@@ -150,10 +150,13 @@ int mq_scene_set_texture(mq_ctx* ctx, uint32_t texnum, uint32_t w, uint32_t h,
  * Builder" node fed by tlas_info (res/default_config.json:3-20,400-403).  As in the reference
  * (src/game/quake_node.cpp:847-983: static geometry is built at map load, per-frame geometry every
  * frame) slots flagged MQ_GEO_STATIC form one tree that is rebuilt and uploaded only when one of them
- * (or a texture) changed; the other slots form a second tree under the same root that every commit
- * rebuilds -- a commit after changing only non-static slots rewrites just that part of the device
- * arrays.  The call waits for frames in flight. */
+ * (or a texture) changed; the other slots form a second tree, stored behind the first, that every
+ * commit rebuilds -- a commit after changing only non-static slots rewrites just that part of the
+ * device arrays.  Rays visit the second tree after the first.  The call waits for frames in flight. */
 int mq_scene_commit(mq_ctx* ctx);
+/* nodes [0, static_nodes) / triangles [0, static_tris) of mq_scene_get_bvh are the static tree (root 0); the
+ * per-frame tree follows (root = node static_nodes) */
+int mq_scene_layout(const mq_ctx* ctx, uint64_t* static_nodes, uint64_t* static_tris);
 /* how many commits took the full path and how many only rewrote the per-frame part */
 int mq_scene_commit_counts(const mq_ctx* ctx, uint32_t* full, uint32_t* per_frame);
 /* QuakeRenderInfo::constant + constant_data_update, src/game/quake_node.hpp:62-84 */

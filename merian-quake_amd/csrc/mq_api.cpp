@@ -63,8 +63,8 @@ struct mq_ctx {
     std::vector<MqNode> s_nodes; std::vector<MqTri> s_tris; // the static tree as built
     float s_sah = 0.0f;
     bool static_dirty = true, tex_dirty = true;
-    bool joined = false;               // layout of nodes / the device arrays
-    uint32_t static_root_children = 0; // internal children of the static root (joined layout: the per-frame root follows them)
+    bool joined = false;               // both trees present
+    uint32_t n_static_nodes = 0, n_static_tris = 0; // the static part of nodes / tris
     uint32_t dev_static_nodes = 0, dev_static_tris = 0; // static part present in the device arrays (joined layout)
     bool dev_scene_valid = false;
     std::vector<MqTexDesc> texdesc;    // of the last full commit: shading records of per-frame triangles need them
@@ -584,40 +584,22 @@ int mq_scene_commit(mq_ctx* c) {
     const bool static_rebuilt = c->static_dirty;
     if (c->static_dirty) {
         flatten_slots(c, true, flat);
-        if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, &c->s_sah, err, 7)) return fail(c, MQ_EINVAL, "bvh build: " + err); // slot 7 of the root stays free for the per-frame tree
+        if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, &c->s_sah, err)) return fail(c, MQ_EINVAL, "bvh build: " + err);
         c->static_dirty = false;
     }
     std::vector<MqNode> d_nodes; std::vector<MqTri> d_tris; float d_sah = 0.0f;
     flatten_slots(c, false, flat);
     if (!mq_build_cwbvh(flat, d_nodes, d_tris, &d_sah, err)) return fail(c, MQ_EINVAL, "bvh build: " + err);
     const size_t ns = c->s_nodes.size(), nd = d_nodes.size(), ts = c->s_tris.size(), td = d_tris.size();
+    // layout: the static tree as built, then the per-frame tree (indices offset); the traversal starts at node 0 and
+    // visits the per-frame root (MqSceneDev::dyn_root) last.  Without static geometry the per-frame tree is the tree.
     const bool joined = ns != 0 && nd != 0;
-    // joined layout: [root, the static root's internal children (ki of them), the per-frame root, the other static
-    // nodes, the other per-frame nodes]; triangles of the static tree, then of the per-frame tree.  What lies behind
-    // the static part can be rewritten in place when the static part did not move.
-    const bool in_place = joined && c->joined && !static_rebuilt && c->nodes.size() >= ns + 1 && c->tris.size() >= ts;
-    if (!joined) {
-        c->nodes = ns ? c->s_nodes : d_nodes; c->tris = ns ? c->s_tris : d_tris;
-    } else {
-        MqNode root; uint32_t rank[8] = {}, ki = 0;
-        if (!mq_merge_root(c->s_nodes[0], d_nodes[0], root, rank, &ki)) return fail(c, MQ_EINVAL, "bvh build: static root is full");
-        if (!in_place) {
-            c->nodes.assign(ns + 1, MqNode());
-            for (size_t i = 1; i < ns; i++) {
-                MqNode n = c->s_nodes[i]; n.child_base += 1; // only the root has children among [1, ki]
-                c->nodes[i <= ki ? 1 + rank[i - 1] : i + 1] = n;
-            }
-            c->tris = c->s_tris;
-        }
-        c->static_root_children = ki;
-        c->nodes.resize(ns + nd); c->tris.resize(ts + td);
-        c->nodes[0] = root;
-        for (size_t j = 0; j < nd; j++) {
-            MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ts;
-            c->nodes[j == 0 ? 1 + ki : ns + j] = n;
-        }
-        std::copy(d_tris.begin(), d_tris.end(), c->tris.begin() + (ptrdiff_t)ts);
-    }
+    const bool in_place = !static_rebuilt && c->nodes.size() >= ns && c->tris.size() >= ts; // the static part is where it was
+    if (!in_place) { c->nodes = c->s_nodes; c->tris = c->s_tris; }
+    c->nodes.resize(ns + nd); c->tris.resize(ts + td);
+    for (size_t j = 0; j < nd; j++) { MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ts; c->nodes[ns + j] = n; }
+    std::copy(d_tris.begin(), d_tris.end(), c->tris.begin() + (ptrdiff_t)ts);
+    c->n_static_nodes = (uint32_t)ns; c->n_static_tris = (uint32_t)ts;
     c->joined = joined;
     c->sah_cost = c->s_sah + d_sah;
     c->committed = true;
@@ -630,22 +612,20 @@ int mq_scene_commit(mq_ctx* c) {
     if (partial) { // per-frame geometry only: root pair, the per-frame tree, its triangles and shading records
         std::vector<MqShadeRec> recs;
         shade_records(c, c->tris.data() + ts, td, recs);
-        const uint32_t ki = c->static_root_children;
-        HIPCHK(c, hipMemcpy(c->d_nodes.p, c->nodes.data(), sizeof(MqNode), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy((MqNode*)c->d_nodes.p + (1 + ki), c->nodes.data() + (1 + ki), sizeof(MqNode), hipMemcpyHostToDevice));
-        if (nd > 1) HIPCHK(c, hipMemcpy((MqNode*)c->d_nodes.p + (ns + 1), c->nodes.data() + (ns + 1), (nd - 1) * sizeof(MqNode), hipMemcpyHostToDevice));
+        if (nd) HIPCHK(c, hipMemcpy((MqNode*)c->d_nodes.p + ns, c->nodes.data() + ns, nd * sizeof(MqNode), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy((MqTri*)c->d_tris.p + ts, c->tris.data() + ts, td * sizeof(MqTri), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy((MqShadeRec*)c->d_shade.p + ts, recs.data(), td * sizeof(MqShadeRec), hipMemcpyHostToDevice));
         if ((r = upload_slot_arrays(c, false))) return r;
         c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
+        c->scene.dyn_root = joined ? (uint32_t)ns : MQ_NIL;
         c->commits_dynamic++;
         return MQ_OK;
     }
     c->dev_scene_valid = false;
     free_scene_dev(c);
-    memset(&c->scene, 0, sizeof c->scene);
+    memset(&c->scene, 0, sizeof c->scene); c->scene.dyn_root = MQ_NIL;
     // room for the per-frame part to grow without another full upload
-    const size_t slack_tris = joined ? td + 16384 : 0, slack_nodes = joined ? nd + 8192 : 0;
+    const size_t slack_tris = td + 16384, slack_nodes = nd + 8192;
     if ((r = dev_alloc(c, c->d_nodes, (c->nodes.size() + slack_nodes) * sizeof(MqNode)))) return r;
     if ((r = dev_alloc(c, c->d_tris, (c->tris.size() + slack_tris) * sizeof(MqTri)))) return r;
     if ((r = dev_alloc(c, c->d_shade, (c->tris.size() + slack_tris) * sizeof(MqShadeRec)))) return r;
@@ -708,9 +688,16 @@ int mq_scene_commit(mq_ctx* c) {
     c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p; c->scene.shade = (const MqShadeRec*)c->d_shade.p;
     c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const float4*)c->d_texels.p;
     c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
+    c->scene.dyn_root = joined ? (uint32_t)ns : MQ_NIL;
     c->tex_dirty = false; c->dev_scene_valid = true;
-    c->dev_static_nodes = joined ? (uint32_t)ns : 0; c->dev_static_tris = joined ? (uint32_t)ts : 0;
+    c->dev_static_nodes = (uint32_t)ns; c->dev_static_tris = (uint32_t)ts;
     c->commits_full++;
+    return MQ_OK;
+}
+
+int mq_scene_layout(const mq_ctx* c, uint64_t* static_nodes, uint64_t* static_tris) {
+    if (!c) return MQ_EINVAL;
+    if (static_nodes) *static_nodes = c->n_static_nodes; if (static_tris) *static_tris = c->n_static_tris;
     return MQ_OK;
 }
 

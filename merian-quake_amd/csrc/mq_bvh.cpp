@@ -105,7 +105,7 @@ inline float exp2i(int e) { uint32_t b = (uint32_t)(e + 127) << 23; float f; mem
 
 // Build into `out_nodes` / `out_tris` (triangles re-ordered into leaf order). `pad` widens every
 // box so the float slab test stays conservative next to the exact triangle test.
-bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err, int root_children) {
+bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err) {
     out_nodes.clear(); out_tris.clear();
     if (sah_cost) *sah_cost = 0.0f;
     const uint32_t n = (uint32_t)tris.size();
@@ -144,7 +144,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
         if (bn.count > 0) { ch[nc++] = w.bnode; } // root that is a leaf
         else { ch[nc++] = bn.left; ch[nc++] = bn.right; }
         for (;;) {
-            if (nc >= (w.out_index == 0 ? root_children : 8)) break; // the root may have to keep a slot free, see mq_merge_root
+            if (nc >= 8) break;
             int best = -1; float ba = -1.0f;
             for (int i = 0; i < nc; i++) {
                 const BNode& c = B.nodes[ch[i]];
@@ -232,96 +232,3 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
     return true;
 }
 
-namespace {
-// the box a node's children decode to, with exactly the planes the traversal kernel uses (p + q * 2^e)
-AABB decoded_box(const MqNode& n) {
-    AABB b; b.reset();
-    const float e[3] = {exp2i((int)n.ex - 127), exp2i((int)n.ey - 127), exp2i((int)n.ez - 127)};
-    const float p[3] = {n.px, n.py, n.pz};
-    const uint8_t* qlo[3] = {n.qlox, n.qloy, n.qloz};
-    const uint8_t* qhi[3] = {n.qhix, n.qhiy, n.qhiz};
-    for (int s = 0; s < 8; s++) {
-        if (n.meta[s] == 0) continue;
-        float lo[3], hi[3];
-        for (int a = 0; a < 3; a++) { lo[a] = p[a] + (float)qlo[a][s] * e[a]; hi[a] = p[a] + (float)qhi[a][s] * e[a]; }
-        b.grow(lo); b.grow(hi);
-    }
-    return b;
-}
-} // namespace
-
-// One root over two trees: the static part of the level and the per-frame geometry (the reference keeps both
-// under one top-level structure and rebuilds only the per-frame part, src/game/quake_node.cpp:847-983).  The root of
-// the static tree (built with at most 7 children) takes the root of the per-frame tree as its child in slot 7, so a
-// ray pays no extra step for the split.  Its children are re-quantised over the union box from their decoded boxes.
-// rank[k] = new position, among the root's internal children, of the static child that had position k; the
-// per-frame root comes after all of them (position *n_internal).  Returns false if the static root is full.
-bool mq_merge_root(const MqNode& rs, const MqNode& rd, MqNode& out, uint32_t rank[8], uint32_t* n_internal) {
-    int slot_of[8]; int n = 0; // old slot of child i
-    for (int s = 0; s < 8; s++) if (rs.meta[s] != 0) slot_of[n++] = s;
-    if (n > 7) return false;
-    int new_slot[8];
-    for (int i = 0; i < n; i++) new_slot[i] = slot_of[i];
-    if (rs.meta[7] != 0) { // free slot 7: its child moves to the lowest empty slot
-        int f = 0; while (rs.meta[f] != 0) f++;
-        new_slot[n - 1] = f; // slot_of is ascending, so the child of slot 7 is the last one
-    }
-    const float es[3] = {exp2i((int)rs.ex - 127), exp2i((int)rs.ey - 127), exp2i((int)rs.ez - 127)};
-    const float ps[3] = {rs.px, rs.py, rs.pz};
-    const uint8_t* sqlo[3] = {rs.qlox, rs.qloy, rs.qloz};
-    const uint8_t* sqhi[3] = {rs.qhix, rs.qhiy, rs.qhiz};
-    AABB box[8], pb; pb.reset();
-    for (int i = 0; i < n; i++) {
-        for (int a = 0; a < 3; a++) { box[i].lo[a] = ps[a] + (float)sqlo[a][slot_of[i]] * es[a]; box[i].hi[a] = ps[a] + (float)sqhi[a][slot_of[i]] * es[a]; }
-        pb.grow(box[i]);
-    }
-    const AABB dbox = decoded_box(rd);
-    pb.grow(dbox);
-    float maxabs = 1.0f;
-    for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs(pb.lo[a]), std::fabs(pb.hi[a])));
-    const float pad = std::max(1e-4f, maxabs * 4.76837158203125e-07f);
-    memset(&out, 0, sizeof out);
-    float lo[3], hi[3]; int ex[3];
-    for (int a = 0; a < 3; a++) {
-        lo[a] = pb.lo[a] - pad; hi[a] = pb.hi[a] + pad;
-        const float ext = std::max(hi[a] - lo[a], 1e-30f);
-        int e = (int)std::ceil(std::log2((double)ext / 255.0));
-        while (lo[a] + 255.0f * exp2i(e) < hi[a]) e++;
-        ex[a] = std::max(-126, std::min(127, e));
-    }
-    out.px = lo[0]; out.py = lo[1]; out.pz = lo[2];
-    out.ex = (uint8_t)(ex[0] + 127); out.ey = (uint8_t)(ex[1] + 127); out.ez = (uint8_t)(ex[2] + 127);
-    out.child_base = 1; out.tri_base = rs.tri_base;
-    uint8_t* qlo[3] = {out.qlox, out.qloy, out.qloz};
-    uint8_t* qhi[3] = {out.qhix, out.qhiy, out.qhiz};
-    for (int s = 0; s < 8; s++) for (int a = 0; a < 3; a++) { qlo[a][s] = 255; qhi[a][s] = 0; }
-    auto quantise = [&](const AABB& b, int s) { // the decoded boxes already carry their tree's padding
-        for (int a = 0; a < 3; a++) {
-            const float e = exp2i(ex[a]);
-            int ql = (int)std::floor(((double)b.lo[a] - (double)lo[a]) / (double)e);
-            int qh = (int)std::ceil(((double)b.hi[a] - (double)lo[a]) / (double)e);
-            ql = std::max(0, std::min(255, ql)); qh = std::max(0, std::min(255, qh));
-            while (ql > 0 && lo[a] + (float)ql * e > b.lo[a]) ql--;
-            while (qh < 255 && lo[a] + (float)qh * e < b.hi[a]) qh++;
-            qlo[a][s] = (uint8_t)ql; qhi[a][s] = (uint8_t)qh;
-        }
-    };
-    for (int i = 0; i < n; i++) {
-        const int s = new_slot[i];
-        quantise(box[i], s);
-        const uint8_t m = rs.meta[slot_of[i]];
-        if ((rs.imask >> slot_of[i]) & 1) { out.imask |= (uint8_t)(1u << s); out.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s)); }
-        else out.meta[s] = m; // leaf: triangle count and offset from tri_base stay
-    }
-    quantise(dbox, 7);
-    out.imask |= 0x80u; out.meta[7] = (uint8_t)((1u << 5) | 31u);
-    uint32_t ki = 0;
-    for (int i = 0; i < n; i++) {
-        if (!((rs.imask >> slot_of[i]) & 1)) continue;
-        const uint32_t old_rank = (uint32_t)__builtin_popcount(rs.imask & ((1u << slot_of[i]) - 1u));
-        rank[old_rank] = (uint32_t)__builtin_popcount(out.imask & ((1u << new_slot[i]) - 1u));
-        ki++;
-    }
-    *n_internal = ki;
-    return true;
-}

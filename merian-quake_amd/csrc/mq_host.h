@@ -77,8 +77,7 @@ struct MqProps {
     bool quirk_n16_wrap = false;
 };
 
-bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err, int root_children = 8);
-bool mq_merge_root(const MqNode& static_root, const MqNode& per_frame_root, MqNode& out, uint32_t rank[8], uint32_t* n_internal);
+bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err);
 
 struct mq_ctx;
 bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string& err);

@@ -272,6 +272,12 @@ MQ_DEV void trav_init(Trav& t, f3 o, f3 d) { // rays end at MQ_T_MAX (raytrace.g
     t.tmask = 0; t.tbase = 0;
 }
 
+// The per-frame tree (quake_node.cpp:896-983) hangs under no node of the static tree: its root waits at the bottom
+// of the ray's stack, so it is visited last, when the closest static hit already bounds it.  After trav_init.
+MQ_DEV void trav_defer(const MqSceneDev& sc, Trav& t, uint2* stk) {
+    if (sc.dyn_root != MQ_NIL) { stk[0] = make_uint2(sc.dyn_root, 0x80000000u); t.sp = 1; }
+}
+
 // One node visit: pops the nearest pending child, intersects its 8 children; the triangles of the
 // leaves that were hit are left in t.tmask / t.tbase.  Precondition: t.G has a pending child.
 template <bool COUNT>
@@ -363,6 +369,7 @@ template <bool COUNT>
 MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, RayHit& hit, uint2* stk, unsigned long long* spill, Ctr& ctr) {
     Trav t;
     trav_init(t, o, d);
+    trav_defer(sc, t, stk);
     if (COUNT) ctr.rays++;
     if (sc.n_nodes != 0) while (!trav_step<COUNT>(sc, t, stk, spill, ctr)) {}
     hit = t.hit;
@@ -1152,6 +1159,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
                 q = shard_pos(pool_s, (pool_j << 6) + i); // the lane is busy from here on
                 float4 o = F.rays[q], d = F.rays[(size_t)F.ray_cap + q];
                 trav_init(t, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z));
+                trav_defer(sc, t, stk);
                 fin = false;
                 if (COUNT) ctr.rays++;
 #ifdef MQ_PROF

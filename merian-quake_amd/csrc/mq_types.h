@@ -167,6 +167,7 @@ struct MqSceneDev {
     const MqTexDesc* tex;
     const float4* texels; // linear RGBA32F, decoded at commit
     uint32_t n_nodes, n_tris;
+    uint32_t dyn_root; // root of the per-frame tree (visited after the static tree), MQ_NIL if there is none
 };
 
 // 16-byte distance Markov-chain state, grid.h:48-52

@@ -101,6 +101,7 @@ def load_library(path=None):
         "mq_scene_get_geometry": (i32, [P, i32, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(vp), C.POINTER(vp), u32p, u32p]),
         "mq_scene_get_texture": (i32, [P, u32, u32p, u32p, C.POINTER(vp), u32p]),
         "mq_scene_get_bvh": (i32, [P, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]),
+        "mq_scene_layout": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mq_scene_commit_counts": (i32, [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "mq_scene_stats": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]),
         "mq_describe": (i32, [P, u32, u32, C.POINTER(IoDesc)]),
@@ -209,6 +210,11 @@ class Context:
 
     def commit(self):
         self._chk(self.lib.mq_scene_commit(self.h))
+
+    def scene_layout(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.mq_scene_layout(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def commit_counts(self):
         a, b = C.c_uint32(), C.c_uint32()

@@ -187,20 +187,26 @@ def test_cwbvh_invariants(mq):
     assert len(tris) == total
     assert len(np.unique(tris["key"])) == total  # every triangle exactly once
     seen_nodes, seen_tris = _walk_bvh(nodes, tris)
+    n_s = ctx.scene_layout()[0]
+    if n_s < len(nodes):  # the per-frame tree has its own root behind the static tree
+        more = _walk_bvh(nodes, tris, n_s)
+        assert not (seen_nodes & more[0]) and not (seen_tris & more[1])
+        seen_nodes |= more[0]; seen_tris |= more[1]
     assert len(seen_nodes) == len(nodes) and len(seen_tris) == len(tris)
     st = ctx.scene_stats()
     assert st["bvh_bytes"] == len(nodes) * 80 + len(tris) * 48
 
 
-def test_static_and_per_frame_trees_share_one_root(mq):
-    """Static slots and per-frame slots are two trees under one root (quake_node.cpp:847-983): the per-frame root is the
-    child in slot 7 of the static root.  Replacing a per-frame slot leaves the static part of the arrays untouched."""
+def test_static_and_per_frame_trees(mq):
+    """Static slots and per-frame slots are two trees (quake_node.cpp:847-983): the per-frame tree is stored behind the
+    static one and replacing a per-frame slot leaves the static part of the arrays untouched."""
     ctx = mq.Context(-1)
     ctx.synth_scene("synth_tiny", 2)
     ctx.commit()
-    n_static = len(ctx.get_bvh()[1])
+    nodes0, tris0 = ctx.get_bvh()
+    n_static = len(tris0)
+    assert ctx.scene_layout() == (len(nodes0), n_static)
     ext0 = ctx.get_geometry(0)["ext"][:1]
-    snapshots = []
     for step, n_tri in enumerate((5, 40, 3)):
         rng = np.random.default_rng(step)
         vtx = (rng.random((3 * n_tri, 3), dtype=np.float32) * 200 - 100).astype(np.float32)
@@ -208,23 +214,17 @@ def test_static_and_per_frame_trees_share_one_root(mq):
         ctx.set_geometry(4, vtx, vtx + 1.0, idx, np.repeat(ext0, n_tri), mq.MQ_GEO_OPAQUE)
         ctx.commit()
         nodes, tris = ctx.get_bvh()
-        assert len(tris) == n_static + n_tri
-        root = nodes[0]
-        assert int(root["meta"][7]) == 32 + 31 and int(root["imask"]) & 0x80 and int(root["child_base"]) == 1
-        per_frame_root = 1 + bin(int(root["imask"]) & 0x7f).count("1")  # after the static root's internal children
-        seen_nodes, seen_tris = _walk_bvh(nodes, tris)
-        assert len(seen_nodes) == len(nodes) and len(seen_tris) == len(tris)
-        d_nodes, d_tris = _walk_bvh(nodes, tris, per_frame_root)
-        s_nodes = seen_nodes - d_nodes - {0}
-        assert d_tris == set(range(n_static, n_static + n_tri))
+        assert len(tris) == n_static + n_tri and ctx.scene_layout() == (len(nodes0), n_static)
+        assert nodes[:len(nodes0)].tobytes() == nodes0.tobytes() and tris[:n_static].tobytes() == tris0.tobytes()
+        s_nodes, s_tris = _walk_bvh(nodes, tris, 0)
+        d_nodes, d_tris = _walk_bvh(nodes, tris, len(nodes0))  # the per-frame root
+        assert s_nodes == set(range(len(nodes0))) and d_nodes == set(range(len(nodes0), len(nodes)))
+        assert s_tris == set(range(n_static)) and d_tris == set(range(n_static, n_static + n_tri))
         assert ((tris["key"][n_static:] >> 28) == 4).all() and (tris["flags"][n_static:] & 2).all()  # distinct previous positions
-        assert max(s_nodes) < min(d_nodes - {per_frame_root}, default=len(nodes))
-        snapshots.append((nodes[sorted(s_nodes)].tobytes(), tris[:n_static].tobytes()))
-    assert all(sn == snapshots[0] for sn in snapshots)
     ctx.set_geometry(4, np.zeros((0, 3), np.float32), None, np.zeros((0, 3), np.uint32), np.zeros(0, mq.EXT_DTYPE), 0)
     ctx.commit()
     nodes, tris = ctx.get_bvh()
-    assert len(tris) == n_static and len(_walk_bvh(nodes, tris)[0]) == len(nodes)
+    assert nodes.tobytes() == nodes0.tobytes() and tris.tobytes() == tris0.tobytes()
 
 
 def _write_bsp(path, bsp2):
