@@ -9,8 +9,12 @@
 #include "mq_host.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <queue>
 
 namespace {
@@ -38,13 +42,11 @@ struct Builder {
     std::vector<AABB> tbox;
     std::vector<float> cent; // 3 per tri
     std::vector<uint32_t> order;
-    std::vector<BNode> nodes;
+    std::vector<BNode> nodes; // preallocated, 2 per triangle: a subtree over `count` triangles owns the ids [id, id + 2 * count - 1)
 
     explicit Builder(const std::vector<MqTri>& t) : in(t) {}
 
-    int build(uint32_t first, uint32_t count, int depth) {
-        int id = (int)nodes.size();
-        nodes.emplace_back();
+    int build(uint32_t first, uint32_t count, int depth, int id) {
         AABB box; box.reset();
         AABB cbox; cbox.reset();
         for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[order[i]]); cbox.grow(&cent[3 * order[i]]); }
@@ -92,8 +94,18 @@ struct Builder {
             std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
                              [&](uint32_t x, uint32_t y) { float cx = cent[3 * x + a], cy = cent[3 * y + a]; return cx < cy || (cx == cy && x < y); });
         }
-        int l = build(first, mid - first, depth + 1);
-        int r = build(mid, first + count - mid, depth + 1);
+        // the two halves touch disjoint ranges of `order` and their own nodes: the upper levels fork (the collapse
+        // below walks the links, so the result does not depend on which task numbered a node)
+        int l, r;
+        static const int fork_depth = getenv("MQ_BVH_FORK_DEPTH") ? atoi(getenv("MQ_BVH_FORK_DEPTH")) : 5; // 0: single-threaded build
+        if (depth < fork_depth && count >= 4096) {
+            auto left = std::async(std::launch::async, [this, first, mid, depth, id] { return build(first, mid - first, depth + 1, id + 1); });
+            r = build(mid, first + count - mid, depth + 1, id + 2 * (int)(mid - first));
+            l = left.get();
+        } else {
+            l = build(first, mid - first, depth + 1, id + 1);
+            r = build(mid, first + count - mid, depth + 1, id + 2 * (int)(mid - first));
+        }
         nodes[id].left = l; nodes[id].right = r;
         return id;
     }
@@ -125,8 +137,10 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
         B.order[i] = i;
     }
     const float pad = std::max(1e-4f, maxabs * 4.76837158203125e-07f); // 2^-21 * extent
-    B.nodes.reserve(2 * (size_t)n);
-    int root = B.build(0, n, 0);
+    B.nodes.resize(2 * (size_t)n);
+    auto T0 = std::chrono::steady_clock::now();
+    int root = B.build(0, n, 0, 0);
+    auto T1 = std::chrono::steady_clock::now();
 
     // ---- collapse to 8-wide ---------------------------------------------------------------------
     struct Work { int bnode; uint32_t out_index; };
@@ -227,6 +241,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
         }
         out_nodes[w.out_index] = node;
     }
+    if (getenv("MQ_DEBUG_BUILD_TIMES")) fprintf(stderr, "bvh build: %u tris, binary tree %.1f ms, collapse %.1f ms\n", n, std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T1).count());
     if (sah_cost) *sah_cost = (float)sah;
     if (out_tris.size() != n) { err = "internal: triangle count mismatch after collapse"; return false; }
     return true;
