@@ -210,6 +210,7 @@ def main():
     for _ in range(args.warmup):
         step(frame); frame += 1
     sync_all()
+    ctx.timing_set_interval(4)  # per-launch events (the kernel times below) on every 4th timed frame: an event between two launches delays the second
     ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -226,6 +227,8 @@ def main():
     assert n_timed == args.steps
     det = ctx.timing_detail()
     per_round = ctx.timing_rounds()
+    n_detail = ctx.timing_detail_frames()
+    ctx.timing_set_interval(1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -240,8 +243,8 @@ def main():
     c = ctx.counters()
     ctx.enable_counters(False)
     local_pixels = c["pixels"]
-    kms = {"mq_primary_kernel": det["primary_ms"] / n_timed, "mq_trace_queue_kernel": det["trace_ms"] / n_timed,
-           "mq_bounce_kernel": det["bounce_ms"] / n_timed, "mq_apply_kernel": update_sum / n_timed}
+    kms = {"mq_primary_kernel": det["primary_ms"] / n_detail, "mq_trace_queue_kernel": det["trace_ms"] / n_detail,
+           "mq_bounce_kernel": det["bounce_ms"] / n_detail, "mq_apply_kernel": update_sum / n_timed}
     rounds = args.spp * 2  # spp * (max path length - 1) launches of trace + bounce per frame
     # algorithmic bytes per kernel class (SURVEY.md 8d prices)
     prim_rays = c["rays"] - c["queue_rays"]
@@ -265,12 +268,12 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                 "achievable_peak": round(ctx.measure_stream_read(), 1),  # streaming read of 2 GiB on this GPU, GB/s (the 8 TB/s above is the spec figure)
-                "kernel_ms_per_launch": round(dom_ms_per_launch, 4), "launches_per_frame": launches[dom],
+                "kernel_ms_per_launch": round(dom_ms_per_launch, 4), "launches_per_frame": launches[dom], "kernel_timed_frames": n_detail,
                 "algorithmic_bytes_per_launch": int(dom_bytes_per_launch),
                 "frame": {"algorithmic_bytes": int(B), "render_ms": round(pipeline_ms, 4), "achieved": round(B / (pipeline_ms * 1e-3) / 1e9, 1),
                           "frac": round(B / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_sample": round(B / max(1, local_pixels * args.spp), 1)},
                 "kernels_ms_per_frame": {k: round(v, 4) for k, v in kms.items()},
-                "launches_ms": [[round(a / n_timed, 4), round(b / n_timed, 4)] for a, b in per_round[:rounds + 1]],  # [trace, shade] per round; entry 0 = primary
+                "launches_ms": [[round(a / n_detail, 4), round(b / n_detail, 4)] for a, b in per_round[:rounds + 1]],  # [trace, shade] per round; entry 0 = primary
                 "kernels_algorithmic_bytes_per_frame": {k: int(v) for k, v in kbytes.items()}, "counters": c}
 
     out = {"metric": "Msamples/s at 1920x1080 1spp (ad_sepulcher); per-pixel L2 vs reference", "value": round(value, 3),

@@ -189,6 +189,11 @@ int mq_last_frame_ms(mq_ctx* ctx, float* total_ms, float* render_ms, float* upda
  * render_mcpg.cpp:255 */
 int mq_timing_reset(mq_ctx* ctx);
 int mq_timing_get(mq_ctx* ctx, uint32_t* frames, double* render_ms_sum, double* update_ms_sum);
+/* The per-launch split below needs an event between every two launches, which costs a few microseconds each:
+ * record them on every `every`-th frame only (default 1 = every frame; frame 0 after a reset is always one).
+ * mq_timing_get covers all frames, _get_detail / _get_rounds the mq_timing_detail_frames() frames with events. */
+int mq_timing_set_interval(mq_ctx* ctx, uint32_t every);
+int mq_timing_detail_frames(mq_ctx* ctx, uint32_t* frames);
 /* the render time split by kernel class: primary (first hit), trace (BVH traversal of bounce rays), bounce (shading/guiding) */
 int mq_timing_get_detail(mq_ctx* ctx, double* primary_ms_sum, double* trace_ms_sum, double* bounce_ms_sum);
 /* per launch: entry 0 = (trace of the primary rays, first-hit shading), entry 1 + r = (trace, bounce) of

@@ -104,6 +104,9 @@ struct mq_ctx {
     double t_render_sum = 0.0, t_update_sum = 0.0; uint32_t t_frames = 0;
     float last_render_ms = 0.0f, last_update_ms = 0.0f;
     bool ev_valid = false;
+    bool volume_outputs_zero = false; // "volume" and its tile copy hold zeros: no need to clear them again
+    bool ev_detail[EV_RING] = {};     // the slot's frame recorded the per-launch events
+    uint32_t ev_counter = 0, t_detail_frames = 0, timing_interval = 1;
     hipStream_t last_stream = nullptr;
     mq_ctx() : tex(MQ_MAX_GLTEXTURES) {}
 };
@@ -774,7 +777,7 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     HIPCHK(c, hipMemset(c->d_prev_vdepth.p, 0, c->d_prev_vdepth.bytes));
     c->dist_mc_n = (uint32_t)(d.state_bytes_volume_distancemc / sizeof(MqDistMC));
     if ((r = dev_alloc(c, c->d_dist_mc, d.state_bytes_volume_distancemc))) return r;
-    c->iteration = 0; c->connected = true; c->params_dirty = true;
+    c->iteration = 0; c->connected = true; c->params_dirty = true; c->volume_outputs_zero = true; // outputs were cleared above
     return MQ_OK;
 }
 
@@ -783,6 +786,15 @@ static int drain_slot(mq_ctx* c, int slot) {
     const int R = c->ev_rounds[slot], last = 3 + 2 * R;
     HIPCHK(c, hipEventSynchronize(c->evr[slot][last]));
     float prim = 0, tr = 0, bo = 0, ap = 0, x = 0;
+    if (!c->ev_detail[slot]) { // only frame start, end of the render passes, end of the update passes
+        HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][0], c->evr[slot][2 + 2 * R]));
+        HIPCHK(c, hipEventElapsedTime(&ap, c->evr[slot][2 + 2 * R], c->evr[slot][last]));
+        c->t_render_sum += x; c->t_update_sum += ap; c->t_frames++;
+        if (slot == c->ev_last) { c->last_render_ms = x; c->last_update_ms = ap; }
+        c->ev_pending[slot] = false;
+        return MQ_OK;
+    }
+    c->t_detail_frames++;
     HIPCHK(c, hipEventElapsedTime(&tr, c->evr[slot][0], c->evr[slot][1]));   // no separate primary-ray launch: ~0
     HIPCHK(c, hipEventElapsedTime(&prim, c->evr[slot][1], c->evr[slot][2]));
     c->t_round_trace[0] += tr; c->t_round_shade[0] += prim;
@@ -881,18 +893,20 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     const int slot = c->ev_slot;
     { int r = drain_slot(c, slot); if (r) return r; } // the slot's previous frame finished long ago
     hipEvent_t* ev = c->evr[slot];
+    const bool detail = c->ev_counter++ % c->timing_interval == 0; // per-launch events on every k-th frame only: each one costs a few microseconds between two dependent launches
+    c->ev_detail[slot] = detail;
     HIPCHK(c, hipEventRecord(ev[0], s));
-    HIPCHK(c, hipEventRecord(ev[1], s)); // (slot of a separate primary-ray trace launch: none, the primary kernel traces its own rays)
+    if (detail) HIPCHK(c, hipEventRecord(ev[1], s)); // (slot of a separate primary-ray trace launch: none, the primary kernel traces its own rays)
     int e = mq_launch_primary(c->scene, c->params, F, guided, c->count_enabled, c->grid_frame[0], s);
     if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
-    HIPCHK(c, hipEventRecord(ev[2], s));
+    if (detail || timed == 0) HIPCHK(c, hipEventRecord(ev[2], s));
     for (int r = 0; r < rounds; r++) {
         e = mq_launch_trace_queue(c->scene, F, r, c->count_enabled, c->grid_frame[1], s);
         if (e) return fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e));
-        if (r < timed) HIPCHK(c, hipEventRecord(ev[3 + 2 * r], s));
+        if (r < timed && detail) HIPCHK(c, hipEventRecord(ev[3 + 2 * r], s));
         e = mq_launch_bounce(c->scene, c->params, F, r, guided, c->count_enabled, c->grid_frame[2], s);
         if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
-        if (r < timed) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s));
+        if (r < timed && (detail || r == timed - 1)) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s)); // the last one ends the render interval
     }
     if (c->params.debug_output_connected) { // mcpg.comp:212-277: part of the surface pass, i.e. before the update pass
         e = mq_launch_debug_view(c->params, F, c->grid_blocks, s);
@@ -921,9 +935,11 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         }
         e = mq_launch_volume_finish(c->params, F, c->grid_blocks, s);
         if (e) return fail(c, MQ_EHIP, std::string("volume finish launch: ") + hipGetErrorString((hipError_t)e));
-    } else {
+        c->volume_outputs_zero = false;
+    } else if (!c->volume_outputs_zero) {
         HIPCHK(c, hipMemsetAsync(c->d_out[MQ_OUT_VOLUME].p, 0, c->d_out[MQ_OUT_VOLUME].bytes, s));
         HIPCHK(c, hipMemsetAsync(c->d_out[MQ_OUT_VOLUME_TILES].p, 0, c->d_out[MQ_OUT_VOLUME_TILES].bytes, s));
+        c->volume_outputs_zero = true;
     }
     HIPCHK(c, hipEventRecord(ev[3 + 2 * timed], s));
     c->ev_rounds[slot] = timed;
@@ -967,9 +983,21 @@ int mq_timing_reset(mq_ctx* c) {
     if (!c) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
     for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
-    c->t_render_sum = c->t_update_sum = 0.0; c->t_frames = 0;
+    c->t_render_sum = c->t_update_sum = 0.0; c->t_frames = 0; c->t_detail_frames = 0; c->ev_counter = 0;
     c->t_primary_sum = c->t_trace_sum = c->t_bounce_sum = 0.0;
     for (int i = 0; i < MQ_TIMING_ROUNDS; i++) c->t_round_trace[i] = c->t_round_shade[i] = 0.0;
+    return MQ_OK;
+}
+int mq_timing_set_interval(mq_ctx* c, uint32_t every) {
+    if (!c || every == 0) return MQ_EINVAL;
+    c->timing_interval = every;
+    return MQ_OK;
+}
+int mq_timing_detail_frames(mq_ctx* c, uint32_t* frames) {
+    if (!c) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
+    if (frames) *frames = c->t_detail_frames;
     return MQ_OK;
 }
 int mq_timing_get(mq_ctx* c, uint32_t* frames, double* render_ms_sum, double* update_ms_sum) {

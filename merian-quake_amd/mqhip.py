@@ -101,6 +101,8 @@ def load_library(path=None):
         "mq_scene_get_geometry": (i32, [P, i32, C.POINTER(vp), C.POINTER(vp), u32p, C.POINTER(vp), C.POINTER(vp), u32p, u32p]),
         "mq_scene_get_texture": (i32, [P, u32, u32p, u32p, C.POINTER(vp), u32p]),
         "mq_scene_get_bvh": (i32, [P, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]),
+        "mq_timing_set_interval": (i32, [P, C.c_uint32]),
+        "mq_timing_detail_frames": (i32, [P, C.POINTER(C.c_uint32)]),
         "mq_scene_layout": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mq_scene_commit_counts": (i32, [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "mq_scene_stats": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]),
@@ -321,6 +323,14 @@ class Context:
         n, a, b = C.c_uint32(), C.c_double(), C.c_double()
         self._chk(self.lib.mq_timing_get(self.h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value, b.value
+
+    def timing_set_interval(self, every):
+        self._chk(self.lib.mq_timing_set_interval(self.h, every))
+
+    def timing_detail_frames(self):
+        n = C.c_uint32()
+        self._chk(self.lib.mq_timing_detail_frames(self.h, C.byref(n)))
+        return n.value
 
     def timing_detail(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
