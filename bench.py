@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--reference-mode", type=int, default=0)
     ap.add_argument("--volume-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bsp", default=None, help="a user-supplied BSP29 / BSP2 map instead of the synthetic stand-in (camera at the player start); "
+                    "default: $MQ_QUAKE_DIR/id1/maps/<--map>.bsp if that file exists")
+    ap.add_argument("--map", default="ad_sepulcher")
+    ap.add_argument("--palette", default=None, help="gfx/palette.lmp for --bsp (default: the loader's built-in grey ramp)")
     args = ap.parse_args()
 
     import torch
@@ -134,7 +138,15 @@ def main():
              "volume spp": args.volume_spp}  # config 3 has no volumes; config 4 (synth_tears, fog) renders them
     for k, v in props.items():
         ctx.set_property(k, v)
-    ctx.synth_scene(args.scene, args.scene_seed)
+    bsp = args.bsp
+    if bsp is None and os.environ.get("MQ_QUAKE_DIR"):  # real maps only when the user supplies them; nothing ships with the repository
+        cand = os.path.join(os.environ["MQ_QUAKE_DIR"], "id1", "maps", args.map + ".bsp")
+        bsp = cand if os.path.exists(cand) else None
+    if bsp:
+        ctx.load_bsp(bsp, args.palette)
+        args.scene, args.scene_seed = os.path.basename(bsp), 0
+    else:
+        ctx.synth_scene(args.scene, args.scene_seed)
     ctx.commit()
     ctx.set_partition(rank, world)
     ctx.connect(W, H)
@@ -278,9 +290,10 @@ def main():
 
     out = {"metric": "Msamples/s at 1920x1080 1spp (ad_sepulcher); per-pixel L2 vs reference", "value": round(value, 3),
            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%s(seed=%d) stand-in for ad_sepulcher, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
-                                  % (args.scene, args.scene_seed, W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real" if bsp else "synthetic",
+           "config": {"workload": "%s, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
+                                  % ("user-supplied map %s, camera at the player start" % args.scene if bsp else "%s(seed=%d) stand-in for ad_sepulcher" % (args.scene, args.scene_seed),
+                                     W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
                       "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world,
                       "collective": "none" if world == 1 else "%dx RCCL all_gather of %d B/rank per frame%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "")},
            "roofline": roofline}

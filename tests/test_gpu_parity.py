@@ -213,6 +213,7 @@ def test_oracle_bvh_equals_brute_force(gpu_ctx):
     ("synth_tiny", 64, 48, {"spp": 1}),
     ("synth_tiny", 72, 40, {"spp": 3, "max path length": 4}),
     ("synth_start", 160, 120, {"spp": 1}),
+    ("synth_start", 320, 240, {"spp": 1}),  # BASELINE config 1: the start.bsp stand-in at the CPU-runnable size
     ("synth_start", 96, 64, {"spp": 2, "max path length": 2, "hide sun": 0}),
     ("synth_start_fog", 320, 200, {"spp": 1}),
     ("synth_sepulcher", 256, 144, {"spp": 1, "max path length": 4}),
