@@ -53,7 +53,12 @@ struct Ctr {
 // Lap profiling (-DMQ_PROF builds only): PLAP(ctr, i) charges the shader clocks since the previous
 // lap of this wave to section i.  Sections: see tools/prof_sections.py.
 #ifdef MQ_PROF
-MQ_DEV void prof_lap(Ctr& c, int i) { uint32_t t = (uint32_t)__builtin_readcyclecounter(); c.prof[i] += t - c.pt; c.pt = t; }
+MQ_DEV void prof_lap(Ctr& c, int i) {
+    const uint32_t t = (uint32_t)__builtin_readcyclecounter();
+    const int32_t d = (int32_t)(t - c.pt); // two back-to-back reads of the scalar clock can complete out of order: never charge a "negative" lap as 2^32
+    if (d > 0) c.prof[i] += (uint32_t)d;
+    c.pt = t;
+}
 MQ_DEV void prof_start(Ctr& c) { c.pt = (uint32_t)__builtin_readcyclecounter(); }
 MQ_DEV void prof_flush(MqCountersDev* g, const Ctr& c) {
     if ((threadIdx.x & 63) == 0) for (int i = 0; i < MQ_PROF_SECTIONS; i++) if (c.prof[i]) atomicAdd(&g->prof[i], (unsigned long long)c.prof[i]);
@@ -1078,6 +1083,10 @@ template <bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
     const int lane = threadIdx.x & 63;
+#ifdef MQ_PROF
+    __shared__ uint32_t s_hist[MQ_WAVES][64]; // rays by loop iterations, bins of 8
+    s_hist[threadIdx.x >> 6][lane] = 0u;
+#endif
     uint2* stk = &s_stack[threadIdx.x >> 6][0][lane];
     const uint32_t gid = blockIdx.x * MQ_BLOCK + threadIdx.x;
     unsigned long long* spill = F.stack_spill + (size_t)gid * MQ_SPILL_ENTRIES;
@@ -1119,6 +1128,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     int owner = -1;
     bool fin = false;
     PSTART(ctr);
+#ifdef MQ_PROF
+    const uint32_t prof_t0 = ctr.pt;
+#endif
     for (;;) {
         unsigned long long idle = __ballot(!busy);
         PLAP(ctr, 24);
@@ -1250,11 +1262,15 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
             F.ray_hits[q] = make_uint4(t.hit.tri, __float_as_uint(t.hit.t), __float_as_uint(t.hit.u), __float_as_uint(t.hit.v));
             q = MQ_NIL; fin = false;
 #ifdef MQ_PROF
-            atomicAdd(&F.counters->ray_hist[ray_iters / 8u < 63u ? ray_iters / 8u : 63u], 1ull);
+            __hip_atomic_fetch_add(&s_hist[threadIdx.x >> 6][ray_iters / 8u < 63u ? ray_iters / 8u : 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); // per wave in LDS: one global atomic per ray serialises the whole kernel on four cache lines
 #endif
         }
         PLAP(ctr, 29);
     }
+#ifdef MQ_PROF
+    ctr.prof[31] = 1u; ctr.prof[37] = (uint32_t)__builtin_readcyclecounter() - prof_t0; // waves and their lifetimes: the section clocks of a wave must add up to its lifetime
+    { const uint32_t h = s_hist[threadIdx.x >> 6][lane]; if (h) atomicAdd(&F.counters->ray_hist[lane], (unsigned long long)h); }
+#endif
     PFLUSH(F.counters, ctr);
     if (COUNT) { // counted separately so the trace kernel's own algorithmic bytes can be priced
         flush_counters(F.counters, ctr);
