@@ -87,3 +87,28 @@ def test_volume_tiles_reassemble_the_single_gpu_volume_image(mqlib):
     ranks[0].untile_volume(g.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(ranks[0].volume(), full)
+
+
+def test_timing_interval_and_images_do_not_depend_on_it(mqlib):
+    """Per-launch timing events on every k-th frame only (mq_timing_set_interval): the frame count and the totals cover
+    all frames, the per-kernel split the sampled ones, and the rendered images are the same either way."""
+    import mqhip
+    imgs = []
+    for every in (1, 3):
+        ctx = mqhip.Context(0)
+        ctx.header_defaults()
+        ctx.synth_scene("synth_tiny", 2)
+        for k, v in {"randomize seed": 0, "seed": 0x5EED, "reference mode": 1, "adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16}.items():
+            ctx.set_property(k, v)
+        ctx.commit(); ctx.connect(96, 64)
+        ctx.timing_set_interval(every); ctx.timing_reset()
+        for f in range(7):
+            ctx.process(ctx.synth_camera(f))
+        n, render, update = ctx.timing_get()
+        det = ctx.timing_detail()
+        assert n == 7 and render > 0 and update >= 0
+        assert ctx.timing_detail_frames() == (7 if every == 1 else 3)  # frames 0, 3, 6
+        assert 0 < det["primary_ms"] + det["trace_ms"] + det["bounce_ms"] <= render * 1.001
+        imgs.append(ctx.irradiance().copy())
+        ctx.close()
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
