@@ -769,7 +769,7 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_paths, slots * 112))) return r; // 7 fields of 16 bytes (the volume pass uses 6)
     if ((r = dev_alloc(c, c->d_debug_rng, (size_t)c->W * c->H * 4))) return r;
     c->ray_cap = (uint32_t)(2 * slots + 1024); // sharded queues interleave 16 tails: room for shard imbalance
-    if ((r = dev_alloc(c, c->d_rays, (size_t)c->ray_cap * 32))) return r;
+    if ((r = dev_alloc(c, c->d_rays, (size_t)c->ray_cap * 32 * 2))) return r; // two buffers, by round parity (ray_buffer in the kernels)
     if ((r = dev_alloc(c, c->d_ray_hits, (size_t)c->ray_cap * 16))) return r;
     if ((r = dev_alloc(c, c->d_qslots[0], (size_t)c->ray_cap * 4))) return r;
     if ((r = dev_alloc(c, c->d_qslots[1], (size_t)c->ray_cap * 4))) return r;

@@ -960,10 +960,17 @@ MQ_DEV uint32_t queue_append(const MqFrame& F, int round, bool& push) {
     if (push && q >= F.ray_cap) { atomicOr(&F.ctrl[0], 1u); push = false; } // cannot happen with the 2x margin; flagged, never silent
     return q;
 }
+// Rays of round r live in ray buffer r & 1 (origins, then directions: field-major like the path records).  Two
+// buffers because a shading kernel reads the direction of the ray that just returned (position q of ITS round's
+// queue) while other waves of the same launch already write rays of the next round -- whose queue positions start
+// at 0 again: with one buffer a wave could read a direction another wave had just replaced.
+MQ_DEV float4* ray_buffer(const MqFrame& F, int round) { return F.rays + (size_t)(round & 1) * 2u * F.ray_cap; }
+
 MQ_DEV void emit_ray(const MqFrame& F, int round, uint32_t q, uint32_t slot, const Path& p) {
     f3 ro = p.cur.pos - p.cur.wi * 1e-3f; // mcpg.comp:144
-    F.rays[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);               // origins, then directions (field-major like the path records)
-    F.rays[(size_t)F.ray_cap + q] = make_float4(p.wo.x, p.wo.y, p.wo.z, 0.0f);
+    float4* rays = ray_buffer(F, round);
+    rays[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+    rays[(size_t)F.ray_cap + q] = make_float4(p.wo.x, p.wo.y, p.wo.z, 0.0f);
     F.queue_slots[round & 1][q] = slot;
     store_path(F.paths + slot, F.n_slots, p);
 }
@@ -1169,7 +1176,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
             if (!busy && rank < avail) {
                 const uint32_t i = pool_i + rank;
                 q = shard_pos(pool_s, (pool_j << 6) + i); // the lane is busy from here on
-                float4 o = F.rays[q], d = F.rays[(size_t)F.ray_cap + q];
+                const float4* rays = ray_buffer(F, round);
+                float4 o = rays[q], d = rays[(size_t)F.ray_cap + q];
                 trav_init(t, F3(o.x, o.y, o.z), F3(d.x, d.y, d.z));
                 trav_defer(sc, t, stk);
                 fin = false;
@@ -1306,7 +1314,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
         const bool valid = queue_valid(qv, q < n ? q : 0u);
         if (q < n && valid) {
             slot = F.queue_slots[round & 1][q];
-            load_path(F.paths + slot, F.n_slots, F.rays[(size_t)F.ray_cap + q], p);
+            load_path(F.paths + slot, F.n_slots, ray_buffer(F, round)[(size_t)F.ray_cap + q], p);
             uint4 hq = F.ray_hits[q];
             RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
             Hit next; next.wi = p.wo; next.pos = p.cur.pos - p.cur.wi * 1e-3f; next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
@@ -1570,8 +1578,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kerne
         uint32_t q = queue_append(F, round, cont);
         if (cont) {
             f3 ro = cam_pos(U) + first_wi * v.t;
-            F.rays[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-            F.rays[(size_t)F.ray_cap + q] = make_float4(v.wo.x, v.wo.y, v.wo.z, 0.0f);
+            float4* rays = ray_buffer(F, round);
+            rays[q] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+            rays[(size_t)F.ray_cap + q] = make_float4(v.wo.x, v.wo.y, v.wo.z, 0.0f);
             F.queue_slots[round & 1][q] = my;
         }
     }

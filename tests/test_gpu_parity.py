@@ -5,6 +5,8 @@ Bars (DESIGN.md "Parity"): integer / index / half-float outputs bit-exact; refer
 perform the same IEEE operations in the same order; guided mode is statistical (races are part of
 the reference algorithm).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -303,6 +305,55 @@ def test_per_frame_geometry_update_parity(gpu_ctx):
     full1, part1 = ctx.commit_counts()
     assert part1 - part0 >= 3 and full1 - full0 <= 1, "per-frame commits took the full path: %r" % ((full1 - full0, part1 - part0),)
     ctx.set_geometry(5, np.zeros((0, 3), np.float32), None, np.zeros((0, 3), np.uint32), np.zeros(0, mqhip.EXT_DTYPE), 0)
+
+
+def test_full_size_frame_parity(gpu_ctx):
+    """BASELINE config 3 at its full size: the 640 k-triangle stand-in at 1920x1080, one unguided frame, every pixel
+    of the radiance image and of the first-hit records bit-identical to the oracle (which needs a few seconds on the
+    host cores for it)."""
+    import mqhip
+    ctx = gpu_ctx
+    o = make_pair(ctx, "synth_sepulcher", 2, {"reference mode": 1, "spp": 1, "max path length": 3}, 1920, 1080)
+    u = ctx.synth_camera(40)
+    ctx.process(u)
+    o.process(u, threads=os.cpu_count() or 8)
+    img, ref = ctx.irradiance(), o.irradiance()
+    bad = (img.view(np.uint32) != ref.view(np.uint32)).any(-1)
+    assert not bad.any(), "%d of %d pixels not bit-identical, first at %r" % (bad.sum(), bad.size, np.argwhere(bad)[0])
+    assert np.array_equal(ctx.read_output(mqhip.OUT_HITS), o.output(orc.OUT_HITS))
+    assert ref[..., :3].sum() > 0
+
+
+def test_full_size_guided_frame_from_given_state_is_bit_exact(gpu_ctx):
+    """The guided estimator at BASELINE config 3's full size (1920x1080, the 640 k-triangle stand-in, several batches
+    of rays per wave in every launch): the oracle learns at a small resolution (its tables are addressed by world-space
+    hash grids, not by pixels), both sides get that state at full size, and the frozen frame must be bit-identical."""
+    import mqhip
+    ctx = gpu_ctx
+    props = {"reference mode": 0, "spp": 1, "max path length": 3, **SMALL}
+    o = make_pair(ctx, "synth_sepulcher", 2, props, 128, 72)
+    for f in range(4):  # sequential frames: deterministic learning
+        o.process(ctx.synth_camera(36 + f), threads=1)
+    omc, olc = o.state(0).copy(), o.state(1).copy()
+    assert (omc["sum_w"] > 0).sum() > 1000 and (olc["N"] > 0).sum() > 1000
+    W, H = 1920, 1080
+    ctx.connect(W, H); o.connect(W, H)
+    ctx.set_property("debug: freeze learning", 1)
+    p = orc.params_from_ctx(ctx, ctx.get_constants())
+    o.set_params(p)
+    try:
+        u = ctx.synth_camera(39)
+        ctx.process(u); o.process(u, threads=os.cpu_count() or 8)  # the first frame after a connect zeroes the tables
+        o.state(0)[:] = omc; o.state(1)[:] = olc
+        _copy_learned_state(ctx, o)
+        u = ctx.synth_camera(40)
+        ctx.process(u); o.process(u, threads=os.cpu_count() or 8)
+        img, ref = ctx.irradiance(), o.irradiance()
+        bad = (img.view(np.uint32) != ref.view(np.uint32)).any(-1)
+        assert not bad.any(), "%d of %d pixels differ, first %r: %r vs %r" % (bad.sum(), bad.size, np.argwhere(bad)[0], img[bad][0], ref[bad][0])
+        assert ref[..., :3].sum() > 0 and (ref[..., :3].sum(-1) > 0).mean() > 0.3
+    finally:
+        ctx.set_property("debug: freeze learning", 0)
 
 
 def test_clear_pass(gpu_ctx):
