@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("W,H,world", [(96, 64, 2), (70, 44, 3)])
-def test_sharded_frame_equals_single_gpu_frame(mqlib, W, H, world):
+@pytest.mark.parametrize("scene,W,H,world", [("synth_tiny", 96, 64, 2), ("synth_tiny", 70, 44, 3),
+                                             ("synth_sepulcher", 1920, 1080, 8)])  # the bench frame as 8 ranks render it
+def test_sharded_frame_equals_single_gpu_frame(mqlib, scene, W, H, world):
     import torch
     import mqhip
     sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
@@ -22,7 +23,7 @@ def test_sharded_frame_equals_single_gpu_frame(mqlib, W, H, world):
 
     def make(rank, nranks):
         c = mqhip.Context(0)
-        c.synth_scene("synth_tiny", 3)
+        c.synth_scene(scene, 3)
         for k, v in props.items():
             c.set_property(k, v)
         c.commit(); c.set_partition(rank, nranks); c.connect(W, H)
@@ -51,6 +52,8 @@ def test_sharded_frame_equals_single_gpu_frame(mqlib, W, H, world):
     ranks[0].untile(g.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(ranks[0].irradiance(), full)
+    for c in ranks + [single]:
+        c.close()
 
 
 def test_volume_tiles_reassemble_the_single_gpu_volume_image(mqlib):
