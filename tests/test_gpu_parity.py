@@ -357,6 +357,36 @@ def test_full_size_guided_frame_from_given_state_is_bit_exact(gpu_ctx):
         ctx.set_property("debug: freeze learning", 0)
 
 
+def test_full_size_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx):
+    """BASELINE config 4's kind of frame at 1920x1080: guided surface estimator (2 spp) + guided single-scatter volume
+    estimator (2 spp) in the fogged 640 k-triangle stand-in.  Both sides learn for three frames (how does not matter),
+    one frozen frame drains what is still queued, the oracle's tables (Markov chains, light cache, distance chains)
+    are copied to the device, and the next two frames must be bit-identical in `irradiance` and `volume`."""
+    ctx = gpu_ctx
+    W, H = 1920, 1080
+    TH = os.cpu_count() or 8
+    o = make_pair(ctx, "synth_tears", 3, {"reference mode": 0, "spp": 2, "max path length": 3, **VOL, "volume forward project": 0}, W, H)
+    for f in range(3):
+        u = ctx.synth_camera(38 + f)
+        o.process(u, threads=TH); ctx.process(u)
+    assert (o.state(2)["N"] > 0).sum() > 1000 and (o.state(0)["sum_w"] > 0).sum() > 10000
+    ctx.set_property("debug: freeze learning", 1)
+    o.set_params(orc.params_from_ctx(ctx, ctx.get_constants()))
+    try:
+        u = ctx.synth_camera(41)
+        ctx.process(u); o.process(u, threads=TH)
+        _copy_learned_state(ctx, o, with_distance=True)
+        for f in (42, 43):
+            u = ctx.synth_camera(f)
+            ctx.process(u); o.process(u, threads=TH)
+            for name, a, b in (("irradiance", ctx.irradiance(), o.irradiance()), ("volume", ctx.volume(), o.volume())):
+                bad = (a.view(np.uint32) != b.view(np.uint32)).any(-1)
+                assert not bad.any(), "frame %d %s: %d pixels differ, first %r" % (f, name, bad.sum(), np.argwhere(bad)[0])
+                assert b[..., :3].sum() > 0
+    finally:
+        ctx.set_property("debug: freeze learning", 0)
+
+
 def test_clear_pass(gpu_ctx):
     """render == false clears the outputs (clear.comp:15-23)."""
     ctx = gpu_ctx
