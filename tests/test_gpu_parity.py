@@ -387,6 +387,44 @@ def test_full_size_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx):
         ctx.set_property("debug: freeze learning", 0)
 
 
+def test_full_size_guided_learning_is_unbiased(mqlib):
+    """Free-running guided learning (enqueue, link, apply over ~3*10^5 updates per frame, the JSON-default 2 GB
+    tables) at the headline configuration: 1920x1080, 640 k triangles.  Learning is racy by design, so the check is
+    statistical: 64-frame means of a static view, guided against unguided -- same image mean within 2 % (measured:
+    0.1 %), same 64x64-block means within 5 % in the median, and several times more lit pixels per frame."""
+    import mqhip
+    ctx = mqhip.Context(0)
+    ctx.json_defaults()
+    W, H, N = 1920, 1080, 64
+    res = {}
+    for mode in (1, 0):
+        for k, v in {"randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3, "reference mode": mode}.items():
+            ctx.set_property(k, v)
+        ctx.synth_scene("synth_sepulcher", 2); ctx.commit(); ctx.connect(W, H)
+        acc = np.zeros((H, W, 3), np.float64); lit = []
+        u = ctx.synth_camera(40)
+        for f in range(N + 16):
+            u.frame = 1000 + f  # static camera, new random numbers every frame
+            ctx.process(u)
+            if f >= 16:
+                img = ctx.irradiance()[..., :3]
+                assert np.isfinite(img).all()
+                acc += img; lit.append(float((img.sum(-1) > 0).mean()))
+        res[mode] = (acc / N, float(np.mean(lit)))
+    ctx.enable_counters(True)
+    u.frame = 5000; ctx.process(u)
+    c = ctx.counters()
+    ctx.enable_counters(False)
+    ctx.close()
+    assert c["queue_overflow"] == 0 and c["mc_updates_accepted"] > 100000
+    ref, gui = res[1][0], res[0][0]
+    assert abs(ref.mean() - gui.mean()) / ref.mean() < 0.02, (ref.mean(), gui.mean())
+    blk = lambda x: x[:1024].reshape(16, 64, 30, 64, 3).mean((1, 3, 4))
+    rel = np.abs(blk(ref) - blk(gui)) / np.maximum(blk(ref), 1e-3)
+    assert np.median(rel) < 0.05, np.median(rel)
+    assert res[0][1] > 4 * res[1][1], (res[0][1], res[1][1])
+
+
 def test_clear_pass(gpu_ctx):
     """render == false clears the outputs (clear.comp:15-23)."""
     ctx = gpu_ctx
