@@ -6,6 +6,7 @@ perform the same IEEE operations in the same order; guided mode is statistical (
 the reference algorithm).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -415,8 +416,21 @@ def test_full_size_guided_learning_is_unbiased(mqlib):
     u.frame = 5000; ctx.process(u)
     c = ctx.counters()
     ctx.enable_counters(False)
-    ctx.close()
     assert c["queue_overflow"] == 0 and c["mc_updates_accepted"] > 100000
+    # one rank of an 8-way tile partition learns from its own eighth of the samples only: its tiles stay unbiased
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "merian-quake_amd"))
+    import mq_tiles
+    ctx.set_partition(3, 8); ctx.connect(W, H)
+    n_tiles = mq_tiles.tiles_per_rank(W, H, 8)
+    tacc = np.zeros((n_tiles, 64, 3), np.float64)
+    for f in range(N + 16):
+        u.frame = 1000 + f
+        ctx.process(u)
+        if f >= 16:
+            tacc += ctx.read_output(mqhip.OUT_TILES).view(np.float32).reshape(n_tiles, 64, 4)[..., :3]
+    ctx.close()
+    want = mq_tiles.tile_image(np.concatenate([res[1][0], np.zeros((H, W, 1))], -1).astype(np.float32), 3, 8)[..., :3]
+    assert abs(want.mean() - (tacc / N).mean()) / want.mean() < 0.03, (want.mean(), (tacc / N).mean())
     ref, gui = res[1][0], res[0][0]
     assert abs(ref.mean() - gui.mean()) / ref.mean() < 0.02, (ref.mean(), gui.mean())
     blk = lambda x: x[:1024].reshape(16, 64, 30, 64, 3).mean((1, 3, 4))
