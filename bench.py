@@ -248,11 +248,18 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = W * H * args.spp * args.steps / dt / 1e6
 
-    # algorithmic bytes: one instrumented launch of the same kernel on the next frame
+    # algorithmic bytes: instrumented launches of the same kernels on the cameras of four timed frames (the middles of the
+    # quarters of the timed region), averaged -- the fly-through gets heavier along its path, so the one frame after the
+    # timed region would overstate the bytes of the average timed launch
     ctx.enable_counters(True)
-    step(frame); frame += 1
-    torch.cuda.synchronize()
-    c = ctx.counters()
+    c = None
+    n_counted = 4
+    for k in range(n_counted):
+        step(args.warmup + (2 * k + 1) * args.steps // (2 * n_counted))
+        torch.cuda.synchronize()
+        ck = ctx.counters()
+        c = ck if c is None else {key: c[key] + v for key, v in ck.items()}
+    c = {key: (v if key == "queue_overflow" else v // n_counted) for key, v in c.items()}
     ctx.enable_counters(False)
     local_pixels = c["pixels"]
     kms = {"mq_primary_kernel": det["primary_ms"] / n_detail, "mq_trace_queue_kernel": det["trace_ms"] / n_detail,

@@ -10,12 +10,12 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-args="--steps 50 --warmup 20 --no-cpu-baseline"
+args="--no-cpu-baseline" # the default workload, steps and warm-up of `python bench.py` (100 timed frames after 64); the CPU leg does not touch the GPU
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o run --output-format csv -- python3 $root/bench.py $args > $out/bench_under_rocprof.json 2> $out/trace.log
 echo "kernel trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o run --output-format csv -- python3 $root/bench.py $args > /dev/null 2> $out/pmc_fetch.log
 echo "FETCH_SIZE pass done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $out/pmc_write -o run --output-format csv -- python3 $root/bench.py $args > /dev/null 2> $out/pmc_write.log
 echo "WRITE_SIZE pass done"
-timeout -k 10 300 python3 $root/bench.py --steps 50 --warmup 20 > $out/bench.json 2> $out/bench.log
+timeout -k 10 300 python3 $root/bench.py > $out/bench.json 2> $out/bench.log
 echo "plain bench done"
