@@ -23,6 +23,7 @@
 
 // launchers implemented in mq_kernels.hip
 int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s);
+int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s);
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s);
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
@@ -795,9 +796,11 @@ static int drain_slot(mq_ctx* c, int slot) {
         return MQ_OK;
     }
     c->t_detail_frames++;
-    HIPCHK(c, hipEventElapsedTime(&tr, c->evr[slot][0], c->evr[slot][1]));   // no separate primary-ray launch: ~0
+    float ptrace = 0;
+    HIPCHK(c, hipEventElapsedTime(&ptrace, c->evr[slot][0], c->evr[slot][1])); // mq_primary_trace_kernel (~0 in a counting frame: traced inline)
     HIPCHK(c, hipEventElapsedTime(&prim, c->evr[slot][1], c->evr[slot][2]));
-    c->t_round_trace[0] += tr; c->t_round_shade[0] += prim;
+    c->t_round_trace[0] += ptrace; c->t_round_shade[0] += prim;
+    prim += ptrace; // "primary" = both launches of the first hit; "trace" = the queue kernel of the bounce rounds only
     for (int k = 0; k < R; k++) {
         HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][2 + 2 * k], c->evr[slot][3 + 2 * k])); tr += x; c->t_round_trace[1 + k] += x;
         HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][3 + 2 * k], c->evr[slot][4 + 2 * k])); bo += x; c->t_round_shade[1 + k] += x;
@@ -896,8 +899,13 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     const bool detail = c->ev_counter++ % c->timing_interval == 0; // per-launch events on every k-th frame only: each one costs a few microseconds between two dependent launches
     c->ev_detail[slot] = detail;
     HIPCHK(c, hipEventRecord(ev[0], s));
-    if (detail) HIPCHK(c, hipEventRecord(ev[1], s)); // (slot of a separate primary-ray trace launch: none, the primary kernel traces its own rays)
-    int e = mq_launch_primary(c->scene, c->params, F, guided, c->count_enabled, c->grid_frame[0], s);
+    int e = 0;
+    if (!c->count_enabled) { // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
+        e = mq_launch_primary_trace(c->scene, c->params, F, c->grid_frame[1], s);
+        if (e) return fail(c, MQ_EHIP, std::string("primary trace launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    if (detail) HIPCHK(c, hipEventRecord(ev[1], s));
+    e = mq_launch_primary(c->scene, c->params, F, guided, c->count_enabled, c->grid_frame[0], s);
     if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
     if (detail || timed == 0) HIPCHK(c, hipEventRecord(ev[2], s));
     for (int r = 0; r < rounds; r++) {

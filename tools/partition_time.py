@@ -24,6 +24,6 @@ for world in worlds:
     rounds = ctx.timing_rounds()
     ms = (render + update) / n
     base = base or ms
-    print("world %d: %.3f ms per frame (x%.2f of world 1); primary %.3f, trace %s, bounce %s, update %.3f" % (
-        world, ms, base / ms, rounds[0][1] / n, "+".join("%.3f" % (a / n) for a, b in rounds[1:3]), "+".join("%.3f" % (b / n) for a, b in rounds[1:3]), update / n))
+    print("world %d: %.3f ms per frame (x%.2f of world 1); primary %.3f+%.3f, trace %s, bounce %s, update %.3f" % (
+        world, ms, base / ms, rounds[0][0] / n, rounds[0][1] / n, "+".join("%.3f" % (a / n) for a, b in rounds[1:3]), "+".join("%.3f" % (b / n) for a, b in rounds[1:3]), update / n))
     ctx.close()
