@@ -110,7 +110,7 @@ typedef struct mq_counters {
     uint64_t rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels;
     uint64_t queue_rays, queue_nodes, queue_tris; /* the bounce-ray traversal kernel alone */
-    uint64_t queue_overflow;                       /* != 0: a ray queue ran out of room since connect (never expected) */
+    uint64_t queue_overflow;                       /* != 0 since connect (never expected): bit 0 a ray queue, bit 1 the update queue ran out of room */
 } mq_counters;
 
 typedef struct mq_ctx mq_ctx;
@@ -214,6 +214,19 @@ int mq_reset_state(mq_ctx* ctx); /* next process() behaves like iteration 0 */
  * Test hook, with the property "debug: freeze learning": a guided frame from a given state is deterministic. */
 int mq_debug_state_read(mq_ctx* ctx, int which, void* dst_host, size_t bytes);
 int mq_debug_state_write(mq_ctx* ctx, int which, const void* src_host, size_t bytes);
+/* Learning-write log (test hook; property "debug: log learning writes").  While the property is set every learning
+ * write a path PROPOSES during mq_process is appended as one 64-byte record of 16 dwords; with "debug: freeze learning"
+ * also set nothing is stored, so the log is a deterministic function of the given state.  The log holds one frame.
+ *   kind 1, a queued Markov-chain update (mc.glsl:159-184), in the layout of the update queue itself:
+ *           pos[3] weight target[3] id normal[3] T  mv0|mv1<<16  mv2|rank<<16 (rank 0 in the log)  slot  kind
+ *   kind 2, a light-cache store (light_cache.glsl:66-84): chk, rekeyed?, irr0|irr1<<16, irr2|N<<16, ... [14] = cell, [15] = kind
+ *   kind 3, a fast-recovery invalidation (mcpg.comp:175-178, volume.comp:226-229): [14] = slot, [15] = kind
+ *   kind 4, a distance-chain store (volume.comp:213-215): sum_w, N, m0, m1, ... [14] = index, [15] = kind
+ * *n_records = records proposed by the last frame (may exceed what the log could hold). */
+int mq_debug_learn_log_read(mq_ctx* ctx, void* dst_host, size_t cap_records, size_t* n_records);
+/* The update pass alone (render_mcpg.cpp:261-277, compute_updates.comp:56-124) on caller-given queue contents: n records
+ * in the kind-1 layout above with slot and arrival rank (< 10, distinct per slot) filled in.  Synchronous. */
+int mq_debug_apply_updates(mq_ctx* ctx, const void* records, uint32_t n, const mq_uniform* u);
 #define MQ_PROF_SECTION_COUNT 40
 int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 

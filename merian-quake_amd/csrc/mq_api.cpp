@@ -26,7 +26,7 @@ int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F,
 int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s);
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s);
-int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, uint32_t sequential_mc_total, hipStream_t s);
 int mq_launch_debug_view(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_stack_lds_entries();
 int mq_launch_stream_read(const void* src, size_t bytes, uint32_t* sink, int grid, hipStream_t s);
@@ -83,6 +83,8 @@ struct mq_ctx {
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
     DevBuf d_prev_vdepth, d_dist_mc;
+    DevBuf d_learn_log, d_learn_count; // "debug: log learning writes": allocated by the first frame that logs
+    uint32_t learn_log_cap = 0;
     uint32_t dist_mc_n = 0;
     uint32_t ray_cap = 0;
     uint32_t queue_cap = 0;
@@ -200,6 +202,8 @@ const PropDesc k_props[] = {
     {"enable emission mipmap", PT_BOOL, POFF(enable_emission_mipmap), false, {}},
     {"debug output connected", PT_BOOL, POFF(debug_output_connected), false, {}},
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
+    {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
+    {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
     {"quirk: 16-bit N*N", PT_BOOL, POFF(quirk_n16_wrap), false, {}},
@@ -306,7 +310,7 @@ void props_to_params(mq_ctx* c) {
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
     P.volume_forward_project = q.volume_forward_project;
-    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning; P.debug_output_connected = q.debug_output_connected;
+    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning; P.log_learning = q.log_learning; P.debug_output_connected = q.debug_output_connected;
     P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
     for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
@@ -319,13 +323,22 @@ void free_frame_state(mq_ctx* c) {
     for (auto& b : c->d_out) dev_free(b);
     dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
-    dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc);
+    dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
 void free_scene_dev(mq_ctx* c) {
     dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels);
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
+}
+
+// Update-queue capacity: one entry per traced segment of the frame (every segment can queue at most one update) plus
+// the slack the 16-way sharded layout needs -- a shard owns every 16th block of 64 positions, so the highest position
+// in use is 1024 * ceil(longest tail / 64), which exceeds the entry count when the shards are out of balance.
+size_t queue_entries_needed(const mq_ctx* c) {
+    const size_t local_px = (size_t)c->tiles_per_rank * 64;
+    const size_t segs = local_px * ((size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1) + (size_t)std::max(0, c->props.volume_spp));
+    return segs + segs / 8 + (size_t)MQ_SHARDS * 64 * 4;
 }
 
 const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8};
@@ -345,7 +358,7 @@ void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     size_t local_px = (size_t)tpr * 64;
     size_t segs = local_px * (size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1);
     segs += local_px * (size_t)std::max(0, c->props.volume_spp); // the volume pass queues Markov-chain updates too
-    d->state_bytes_update_queue = segs * sizeof(MqUpdate);
+    d->state_bytes_update_queue = (segs + segs / 8 + (size_t)MQ_SHARDS * 64 * 4) * sizeof(MqUpdate); // + shard slack, queue_entries_needed()
     const uint32_t gw = (uint32_t)std::max(1, c->props.distance_mc_grid_width); // render_mcpg.cpp:80-82
     d->state_bytes_volume_distancemc = (size_t)(w / gw + 2) * (h / gw + 2) * 10 * sizeof(MqDistMC);
 }
@@ -758,8 +771,7 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_lc, (size_t)c->lc_total * sizeof(MqLCCell)))) return r;
     if ((r = dev_alloc(c, c->d_upd_count, (size_t)c->mc_total * 4))) return r;
     if ((r = dev_alloc(c, c->d_upd_head, (size_t)c->mc_total * 4))) return r;
-    size_t segs = (size_t)c->tiles_per_rank * 64 * ((size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1) + (size_t)std::max(0, c->props.volume_spp));
-    c->queue_cap = (uint32_t)std::min<size_t>(segs, 0x7fffffffu);
+    c->queue_cap = (uint32_t)std::min<size_t>(queue_entries_needed(c), 0x7fffffffu);
     if ((r = dev_alloc(c, c->d_queue, (size_t)c->queue_cap * sizeof(MqUpdate)))) return r;
     if ((r = dev_alloc(c, c->d_ctrl, MQ_CTRL_WORDS * 4))) return r;
     if ((r = dev_alloc(c, c->d_counters, sizeof(MqCountersDev)))) return r;
@@ -830,6 +842,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p; F.ray_cap = c->ray_cap;
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
     F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
+    F.learn_log = (uint4*)c->d_learn_log.p; F.learn_log_count = (uint32_t*)c->d_learn_count.p; F.learn_log_cap = c->learn_log_cap;
     const int K = c->params.reference_mode ? 0 : std::max(0, c->params.mc_samples);
     F.lds_rows2 = (uint32_t)std::max(mq_stack_lds_entries(), (6 * K + 1) / 2);
 }
@@ -859,6 +872,34 @@ static int frame_grids(mq_ctx* c, const MqFrame& F) {
     return MQ_OK;
 }
 
+// "spp", "max path length" and "volume spp" do not need a reconnect (render_mcpg.cpp:567-575 lists what does), but
+// the update queue is sized by them: grown here, between frames, keeping what the volume pass of the last frame queued.
+static int ensure_queue(mq_ctx* c) {
+    const uint32_t need = (uint32_t)std::min<size_t>(queue_entries_needed(c), 0x7fffffffu);
+    if (need <= c->queue_cap) return MQ_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    DevBuf bigger;
+    int r = dev_alloc(c, bigger, (size_t)need * sizeof(MqUpdate));
+    if (r) return r;
+    HIPCHK(c, hipMemcpy(bigger.p, c->d_queue.p, (size_t)c->queue_cap * sizeof(MqUpdate), hipMemcpyDeviceToDevice));
+    dev_free(c->d_queue);
+    c->d_queue = bigger; c->queue_cap = need;
+    return MQ_OK;
+}
+// the learning-write log: room for every write a frame can propose (per segment: one update or invalidation and one
+// light-cache store; per volume sample: an update or invalidation and a distance store)
+static int ensure_learn_log(mq_ctx* c) {
+    const size_t local_px = (size_t)c->tiles_per_rank * 64;
+    const size_t need = 2 * local_px * ((size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1) + (size_t)std::max(0, c->props.volume_spp)) + 1024;
+    if (c->d_learn_log.p && c->learn_log_cap >= need) return MQ_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    int r = dev_alloc(c, c->d_learn_log, need * 64);
+    if (!r && !c->d_learn_count.p) r = dev_alloc(c, c->d_learn_count, 16);
+    if (r) return r;
+    c->learn_log_cap = (uint32_t)std::min<size_t>(need, 0xffffffffu);
+    return MQ_OK;
+}
+
 int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     if (!c || !u) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
@@ -868,6 +909,8 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     c->last_stream = s;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->params_dirty) props_to_params(c);
+    { int r = ensure_queue(c); if (r) return r; }
+    if (c->params.log_learning) { int r = ensure_learn_log(c); if (r) return r; HIPCHK(c, hipMemsetAsync(c->d_learn_count.p, 0, 16, s)); } // the log holds ONE frame
     MqFrame F; fill_frame(c, u, F);
     { int r = frame_grids(c, F); if (r) return r; }
     if (c->iteration == 0) { // render_mcpg.cpp:221-226
@@ -921,7 +964,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         if (e) return fail(c, MQ_EHIP, std::string("debug view launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (guided) { // render_mcpg.cpp:261-277
-        e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, s);
+        e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, c->props.sequential_update_pass ? c->mc_total : 0u, s);
         if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     }
     // ---- volume passes, render_mcpg.cpp:280-320 (their device time is part of the update interval) ----
@@ -1087,6 +1130,45 @@ int mq_debug_state_write(mq_ctx* c, int which, const void* src, size_t bytes) {
     if (c->iteration == 0) return fail(c, MQ_ESTATE, "process one frame before writing state (the first frame zeroes it)");
     HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(b->p, src, bytes, hipMemcpyHostToDevice));
+    return MQ_OK;
+}
+
+int mq_debug_learn_log_read(mq_ctx* c, void* dst, size_t cap_records, size_t* n_records) {
+    if (!c || !n_records) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->d_learn_count.p) { *n_records = 0; return MQ_OK; }
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipDeviceSynchronize());
+    uint32_t n = 0;
+    HIPCHK(c, hipMemcpy(&n, c->d_learn_count.p, 4, hipMemcpyDeviceToHost));
+    *n_records = n; // records proposed; those beyond the log's capacity were counted, not kept
+    const size_t have = std::min<size_t>(n, c->learn_log_cap);
+    if (dst && cap_records) HIPCHK(c, hipMemcpy(dst, c->d_learn_log.p, std::min(have, cap_records) * 64, hipMemcpyDeviceToHost));
+    return MQ_OK;
+}
+
+// mq_link_kernel + mq_apply_kernel alone, on caller-given queue contents (the update pass of render_mcpg.cpp:261-277 /
+// compute_updates.comp:56-124): records in the queue's own 64-byte layout with slot and arrival rank filled in.
+int mq_debug_apply_updates(mq_ctx* c, const void* records, uint32_t n, const mq_uniform* u) {
+    if (!c || !u || (!records && n)) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
+    if (c->iteration == 0) return fail(c, MQ_ESTATE, "process one frame first (the first frame zeroes the tables)");
+    if (n > c->queue_cap) return fail(c, MQ_EINVAL, "more records than the update queue holds");
+    HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipDeviceSynchronize());
+    if (c->params_dirty) props_to_params(c);
+    // positions [0, n) of the sharded queue: shard s owns every 16th block of 64 positions, so its tail is the number
+    // of those positions that fall into its blocks
+    std::vector<uint32_t> ctrl(MQ_CTRL_GROUP, 0u);
+    for (uint32_t p = 0; p < n; p += 64) ctrl[((p >> 6) & (MQ_SHARDS - 1)) * MQ_SHARD_STRIDE] += std::min(64u, n - p);
+    std::vector<MqUpdate> recs((const MqUpdate*)records, (const MqUpdate*)records + n);
+    for (auto& r : recs) { if (r.slot >= c->mc_total || r.rank >= MQ_MAX_UPDATES) return fail(c, MQ_EINVAL, "record with a bad slot or rank"); r.next = 0u; }
+    if (n) HIPCHK(c, hipMemcpy(c->d_queue.p, recs.data(), (size_t)n * sizeof(MqUpdate), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy((uint32_t*)c->d_ctrl.p + MQ_CTRL_UPDATES, ctrl.data(), MQ_CTRL_GROUP * 4, hipMemcpyHostToDevice));
+    MqFrame F; fill_frame(c, u, F);
+    int e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, c->props.sequential_update_pass ? c->mc_total : 0u, nullptr);
+    if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
+    HIPCHK(c, hipMemsetAsync((uint32_t*)c->d_ctrl.p + MQ_CTRL_UPDATES, 0, MQ_CTRL_GROUP * 4, nullptr));
+    HIPCHK(c, hipDeviceSynchronize());
     return MQ_OK;
 }
 

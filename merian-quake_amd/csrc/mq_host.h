@@ -72,9 +72,11 @@ struct MqProps {
     bool enable_emission_mipmap = true;
     bool debug_output_connected = false; // the reference derives this from the graph wiring (render_mcpg.cpp:182-183)
     bool freeze_learning = false; // test hook, not a reference property
-    // named quirk switches
-    bool quirk_lc_max_wo_p = true;
-    bool quirk_n16_wrap = false;
+    bool log_learning = false;    // test hook, not a reference property
+    bool sequential_update_pass = false; // test hook: the update pass in the reference's dispatch order, one slot after the other
+    // named quirk switches: on = what the reference's shaders compute, off = the evident intent
+    bool quirk_lc_max_wo_p = true; // mcpg.comp:170 `max(wo_p, 10)`
+    bool quirk_n16_wrap = true;    // mc.glsl:26 `N * N` on a uint16_t (grid.h:19): wraps, 0 at N = 256 / 512 / 768 / 1024
 };
 
 bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err);

@@ -318,13 +318,6 @@ MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane]
     const uint32_t oct4 = t.oct4;
     uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, oct4) |
                   box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, oct4);
-#ifdef MQ_EXP_DUMMY_VALU // experiment: extra dependent VALU work per node visit (is the kernel issue bound?)
-    { float z[8]; for (int k = 0; k < 8; k++) z[k] = adx + (float)k; for (int i = 0; i < MQ_EXP_DUMMY_VALU / 8; i++) for (int k = 0; k < 8; k++) z[k] = __builtin_fmaf(z[k], ady, adz); // 8 independent chains
-      float zs = 0.0f; for (int k = 0; k < 8; k++) zs += z[k]; if (zs == 123.456f) hm ^= 1u; }
-#endif
-#ifdef MQ_EXP_DUMMY_LOAD // experiment: extra 16-byte gathers per node visit (is the kernel L1 bound?)
-    { uint32_t acc = 0; for (int i = 0; i < MQ_EXP_DUMMY_LOAD; i++) { uint4 x = ((const uint4*)(sc.nodes + ((G.x + rel + 977u * (i + 1)) % sc.n_nodes)))[i % 5]; acc ^= x.x; } if (acc == 0x12345678u) hm ^= 1u; }
-#endif
     G.x = n1.x;
     G.y = (hm & 0xff000000u) | (n0.w >> 24);
     t.G = G;
@@ -623,6 +616,15 @@ MQ_DEV void mc_finalize_load(const mq_uniform& U, MCS& s, uint32_t hash16, bool 
     s.w_tgt = s.w_tgt + F3(h2f(s.mv[0]), h2f(s.mv[1]), h2f(s.mv[2])) * k;
 }
 
+// ---- learning-write log (test hook, property "debug: log learning writes"; record layouts: include/mq.h) ----
+MQ_DEV void learn_log(const MqFrame& F, uint4 a, uint4 b, uint4 c, uint4 d) {
+    const uint32_t at = atomicAdd(F.learn_log_count, 1u);
+    if (at < F.learn_log_cap) { uint4* e = F.learn_log + 4 * (size_t)at; e[0] = a; e[1] = b; e[2] = c; e[3] = d; }
+}
+MQ_DEV void learn_log_simple(const MqFrame& F, uint32_t kind, uint32_t index, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    learn_log(F, make_uint4(a, b, c, d), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, index, kind));
+}
+
 // ---- light cache (light_cache.glsl:31-84) ------------------------------------------------------
 MQ_DEV void lc_address(const MqParams& P, uint32_t& rng, uint32_t level, f3 pos, f3 normal, uint32_t& idx, uint32_t& chk) {
     i3 g = grid_idx_interpolate(pos, lc_inv_width(P, level), xorshift(rng));
@@ -649,7 +651,8 @@ MQ_DEV f3 light_cache_get(const MqParams& P, const mq_uniform& U, const MqLCCell
 // number) and DROPS the update when the lock is contended; this version needs no lock word (see the
 // store below).  Frame 0 cancels every update, as the reference does (its zero-initialised lock
 // word equals params.frame, light_cache.glsl:59-64).
-MQ_DEV void light_cache_update(const MqParams& P, const mq_uniform& U, MqLCCell* lc, uint32_t& rng, f3 pos, f3 normal, f3 irr, Ctr& ctr) {
+MQ_DEV void light_cache_update(const MqParams& P, const MqFrame& F, uint32_t& rng, f3 pos, f3 normal, f3 irr, Ctr& ctr) {
+    const mq_uniform& U = F.u; MqLCCell* const lc = F.lc;
     uint32_t level = lc_level(P, U, pos), idx, chk;
     lc_address(P, rng, level, pos, normal, idx, chk);
     if (U.frame == 0u) { ctr.lc_cancel++; return; }
@@ -667,6 +670,7 @@ MQ_DEV void light_cache_update(const MqParams& P, const mq_uniform& U, MqLCCell*
     float a = mmax(1.0f / (float)N, MQ_LC_MIN_ALPHA);
     uint32_t o0 = f2h(mmix(cur.x, irr.x, a)), o1 = f2h(mmix(cur.y, irr.y, a)), o2 = f2h(mmix(cur.z, irr.z, a));
     const uint32_t nz = o0 | (o1 << 16), nw = o2 | (N << 16);
+    if (P.log_learning) learn_log_simple(F, 2u, idx, chk, rekey ? 1u : 0u, nz, nw);
     if (P.freeze_learning) return;
     // One aligned store publishes the cell: 16 bytes when the cell is (re)keyed, else the 8-byte
     // (irradiance, N) payload.  Two lanes racing on one cell lose one of the two updates -- the
@@ -714,6 +718,11 @@ MQ_DEV void load_chit(const uint32_t* src, Hit& h) { // hit.glsl.h:45-53
 MQ_DEV void enqueue_update(const MqParams& P, const MqFrame& F, uint32_t& rng, uint32_t index, uint32_t id, f3 pos, float w, f3 target, f3 target_mv, f3 normal, Ctr& ctr) {
     const mq_uniform& U = F.u;
     if (index == MQ_NIL) { uint32_t h16; mc_adaptive_buffer_index(P, U, rng, pos, normal, index, h16); }
+    const uint32_t mv01 = (uint32_t)f2h(target_mv.x) | ((uint32_t)f2h(target_mv.y) << 16), mv2 = (uint32_t)f2h(target_mv.z);
+    const uint4 r0 = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(w));
+    const uint4 r1 = make_uint4(__float_as_uint(target.x), __float_as_uint(target.y), __float_as_uint(target.z), id);
+    const uint4 r2 = make_uint4(__float_as_uint(normal.x), __float_as_uint(normal.y), __float_as_uint(normal.z), __float_as_uint(U.cl_time));
+    if (P.log_learning && P.freeze_learning) learn_log(F, r0, r1, r2, make_uint4(mv01, mv2, index, 1u)); // proposed, never queued: no arrival rank
     if (P.freeze_learning) return;
     // Cap (mc.glsl:169-184): the returning increment of the slot's counter is this update's arrival
     // rank; ranks >= MQ_MAX_UPDATES are dropped.  The queue position is allocated at the same time
@@ -731,17 +740,19 @@ MQ_DEV void enqueue_update(const MqParams& P, const MqFrame& F, uint32_t& rng, u
         base = __shfl(base, leader, 64);
         uq = shard_pos(shard, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
     }
+    if (P.log_learning) learn_log(F, r0, r1, r2, make_uint4(mv01, mv2 | ((rank_in_slot < 0xffffu ? rank_in_slot : 0xffffu) << 16), index, 1u)); // with the arrival rank (>= 10: dropped by the cap)
     if (uq < F.queue_cap) {
         uint4* e = (uint4*)(F.queue + uq);
         if (rank_in_slot < MQ_MAX_UPDATES) {
-            e[0] = make_uint4(__float_as_uint(pos.x), __float_as_uint(pos.y), __float_as_uint(pos.z), __float_as_uint(w));
-            e[1] = make_uint4(__float_as_uint(target.x), __float_as_uint(target.y), __float_as_uint(target.z), id);
-            e[2] = make_uint4(__float_as_uint(normal.x), __float_as_uint(normal.y), __float_as_uint(normal.z), __float_as_uint(U.cl_time));
-            e[3] = make_uint4((uint32_t)f2h(target_mv.x) | ((uint32_t)f2h(target_mv.y) << 16), (uint32_t)f2h(target_mv.z), index, 0u);
+            e[0] = r0; e[1] = r1; e[2] = r2;
+            e[3] = make_uint4(mv01, mv2 | (rank_in_slot << 16), index, 0u); // the arrival rank travels with the entry: the update pass replays by rank
         } else {
             e[3] = make_uint4(0u, 0u, MQ_NIL, 0u);
             ctr.upd_drop++;
         }
+    } else { // no room in the queue (never expected: mq_api.cpp sizes it for every segment of the frame plus shard slack): flagged, and the slot's counter is given back
+        atomicOr(&F.ctrl[0], 2u);
+        atomicSub(&F.upd_count[index], 1u);
     }
 }
 
@@ -1347,13 +1358,6 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
             f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
             PLAP(ctr, 17);
             shade_hit(sc, P, U, rhit, throughput, incident, next, sun_color);
-#ifdef MQ_EXP_BOUNCE_VALU // experiment: extra independent VALU work per path (is the shading kernel issue bound?)
-            { float z[8]; for (int k = 0; k < 8; k++) z[k] = throughput.x + (float)k; for (int i = 0; i < MQ_EXP_BOUNCE_VALU / 8; i++) for (int k = 0; k < 8; k++) z[k] = __builtin_fmaf(z[k], throughput.y, throughput.z);
-              float zs = 0.0f; for (int k = 0; k < 8; k++) zs += z[k]; if (zs == 123.456f) incident.x += 1.0f; }
-#endif
-#ifdef MQ_EXP_BOUNCE_LOAD // experiment: extra 16-byte gathers per path (is it bound by the L1 gather path?)
-            { uint32_t acc = 0; for (int i = 0; i < MQ_EXP_BOUNCE_LOAD; i++) { uint4 x = ((const uint4*)(sc.tris + ((rhit.tri + 977u * (i + 1)) % sc.n_tris)))[i % 3]; acc ^= x.x; } if (acc == 0x12345678u) incident.x += 1.0f; }
-#endif
             PLAP(ctr, 18);
             f3 lc_incident; // mcpg.comp:149
             if ((incident.x > 0.0f || incident.y > 0.0f || incident.z > 0.0f) || (P.use_light_cache_tail == 0 && P.max_path_length == 2)) lc_incident = incident;
@@ -1368,14 +1372,15 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
                 float mc_f = luminance((lc_incident * p.bsdf) * (1.0f / p.wo_p));
                 if (mfinite(mc_f)) {
                     float den = P.quirk_lc_max_wo_p ? mmax(p.wo_p, 10.0f) : mmax(p.wo_p, 1e-6f);
-                    light_cache_update(P, U, F.lc, p.rng, p.cur.pos, p.cur.normal, ((lc_incident * (p.cur.albedo * MQ_INV_PI)) * p.wodotn) * (1.0f / den), ctr);
+                    light_cache_update(P, F, p.rng, p.cur.pos, p.cur.normal, ((lc_incident * (p.cur.albedo * MQ_INV_PI)) * p.wodotn) * (1.0f / den), ctr);
                     if (COUNT) ctr.lc++;
                     PLAP(ctr, 20);
                     if (xorshift(p.rng) * p.score_sum < mc_f * (float)P.mc_samples) {
                         f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
                         enqueue_update(P, F, p.rng, p.mc_index, p.mc_id, p.cur.pos, mc_f, next.pos, mv, p.cur.normal, ctr);
-                    } else if (P.mc_fast_recovery && !P.freeze_learning && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
-                        F.mc[p.mc_index].sum_w = 0.0f; // mcpg.comp:177
+                    } else if (P.mc_fast_recovery && p.mc_index != MQ_NIL && !(mc_f > 1e-3f * p.mc_sum_w) && p.lm_dir_ok) {
+                        if (P.log_learning) learn_log_simple(F, 3u, p.mc_index, 0u, 0u, 0u, 0u);
+                        if (!P.freeze_learning) F.mc[p.mc_index].sum_w = 0.0f; // mcpg.comp:177
                     }
                 }
             }
@@ -1659,6 +1664,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel
             }
             if (xorshift(v.rng) < l / (v.dist_score_sum / (float)P.distance_mc_samples)) { // :213
                 const uint32_t di = distance_mc_index(P, F, v.rng, (float)v.px, (float)v.py, grid_max_x);
+                if (P.log_learning) learn_log_simple(F, 4u, di, __float_as_uint(v.ds.sum_w), v.ds.N, __float_as_uint(v.ds.m0), __float_as_uint(v.ds.m1));
                 if (!P.freeze_learning) F.dist_mc[di] = make_float4(v.ds.sum_w, __uint_as_float(v.ds.N), v.ds.m0, v.ds.m1);
             }
             const float mc_f = luminance((incident * phase) * (1.0f / v.wo_p)); // :218
@@ -1667,8 +1673,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel
                 f3 jn = sample_cos_frame(-first_wi, x0, x1);
                 f3 mv = rh3((next.pos - next.prev_pos) * (1.0f / U.cam_w[3]));
                 enqueue_update(P, F, v.rng, v.mc_index, v.mc_id, cur_pos, mc_f, next.pos, mv, jn, ctr);
-            } else if (P.mc_fast_recovery && !P.freeze_learning && v.mc_index != MQ_NIL && !(mc_f > 1e-3f * v.mc_sum_w) && v.lm_dir_ok) {
-                F.mc[v.mc_index].sum_w = 0.0f; // :228
+            } else if (P.mc_fast_recovery && v.mc_index != MQ_NIL && !(mc_f > 1e-3f * v.mc_sum_w) && v.lm_dir_ok) {
+                if (P.log_learning) learn_log_simple(F, 3u, v.mc_index, 0u, 0u, 0u, 0u);
+                if (!P.freeze_learning) F.mc[v.mc_index].sum_w = 0.0f; // :228
             }
         }
         store_vpath(F.paths + slot, F.n_slots, v);
@@ -1719,69 +1726,98 @@ __global__ __launch_bounds__(256) void mq_link_kernel(MqFrame F) {
     }
 }
 
+// One slot of the update pass, compute_updates.comp:56-124: `head` = index of the newest queue entry of `slot` (the chain
+// built by mq_link_kernel).  Returns the number of updates applied.
+MQ_DEV uint32_t apply_slot(const MqParams& P, const MqFrame& F, uint32_t slot, uint32_t i /* head entry */) {
+    const mq_uniform& U = F.u;
+    uint32_t n_applied = 0;
+    // The slot's entries by ARRIVAL RANK (the value the slot counter returned at enqueue, kept in the entry): the
+    // chain links them in the order the link pass happened to see them, the replay below follows the ranks --
+    // compute_updates.comp:73 walks update.ids[0 .. count) in exactly that order.  Only ranks < MQ_MAX_UPDATES
+    // were ever written (mc.glsl:169-184); `present` tolerates holes (an entry lost to a full queue).
+    uint32_t chain[MQ_MAX_UPDATES];
+    uint32_t present = 0u;
+    for (uint32_t at = i + 1u; at != 0u;) {
+        const uint4 q3 = ((const uint4*)(F.queue + (at - 1u)))[3];
+        const uint32_t r = q3.y >> 16;
+        if (r < MQ_MAX_UPDATES) { chain[r] = at - 1u; present |= 1u << r; }
+        at = q3.w;
+    }
+    const uint32_t count = (uint32_t)__popc(present);
+    n_applied = count;
+    uint32_t rng = pcg4d16(slot, 0u, U.frame, P.seed); // :62
+    MCS mc_state = mc_load(F.mc, slot);
+    float sum = 0.0f, upd_T = 0.0f;
+    f3 pos = F3(0, 0, 0), normal = F3(0, 0, 0);
+    MCS new_state = {}; bool picked = false;
+    for (uint32_t m = present; m; m &= m - 1u) {
+        const uint32_t r = (uint32_t)__ffs((int)m) - 1u;
+        const uint4* q = (const uint4*)(F.queue + chain[r]);
+        uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        f3 upos = F3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+        f3 utgt = F3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+        uint16_t mv[3] = {(uint16_t)(q3.x & 0xffffu), (uint16_t)(q3.x >> 16), (uint16_t)(q3.y & 0xffffu)};
+        if (m == present) upd_T = __uint_as_float(q2.w); // the first arrival stamps the slot (mc.glsl:171-173)
+        MCS st = mc_state;
+        if (mc_state.id != q1.w) st = mc_state_new(rng);
+        mc_update(st, upos, __uint_as_float(q0.w), utgt, mv);
+        if (mc_state.id == st.id) mc_state = st;
+        sum += st.sum_w;
+        if (xorshift(rng) < st.sum_w / sum) { new_state = st; pos = upos; normal = F3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)); picked = true; }
+    }
+    new_state.T = upd_T;
+    if (picked) for (uint32_t k = 0; k < count; k++) { // :94-119
+        { uint32_t bi, h16; mc_static_buffer_index(P, rng, pos, bi, h16);
+          new_state.hash = h16; MCS old = mc_load(F.mc, bi);
+          if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
+        { uint32_t bi, h16; mc_adaptive_buffer_index(P, U, rng, pos, normal, bi, h16);
+          new_state.hash = h16; MCS old = mc_load(F.mc, bi);
+          if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
+    }
+    F.upd_head[slot] = 0u; // :121-122
+    F.upd_count[slot] = 0u;
+    return n_applied;
+}
+
 // pass B: the newest entry of a slot leads and replays compute_updates.comp:56-124 for the slot's
 // first MQ_MAX_UPDATES arrivals (the reference drops later arrivals at enqueue time, mc.glsl:169-184)
 __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
-    const mq_uniform& U = F.u;
     const QView qv = queue_view(F.ctrl + MQ_CTRL_UPDATES);
     const uint32_t n = qv.n_eff < F.queue_cap ? qv.n_eff : F.queue_cap;
-    uint32_t accepted = 0, dropped = 0;
+    uint32_t accepted = 0;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
         const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         const bool valid = queue_valid(qv, i < n ? i : 0u);
         if (!(i < n && valid)) continue;
-        const uint4* e = (const uint4*)(F.queue + i);
-        uint4 e3 = e[3];
-        uint32_t slot = e3.z;
+        const uint32_t slot = ((const uint4*)(F.queue + i))[3].z;
         if (slot == MQ_NIL) continue; // dropped by the cap at enqueue (counted there)
         if (*(volatile uint32_t*)&F.upd_head[slot] != i + 1u) continue;
-        // chain length, then skip the newest arrivals beyond the cap
-        uint32_t len = 0, at = i + 1u;
-        while (at != 0u) { len++; at = ((const uint4*)(F.queue + (at - 1u)))[3].w; }
-        uint32_t chain[MQ_MAX_UPDATES];
-        uint32_t count = len < MQ_MAX_UPDATES ? len : MQ_MAX_UPDATES, skip = len - count;
-        at = i + 1u;
-        for (uint32_t k = 0; k < skip; k++) at = ((const uint4*)(F.queue + (at - 1u)))[3].w;
-        for (uint32_t k = 0; k < count; k++) { chain[k] = at - 1u; at = ((const uint4*)(F.queue + (at - 1u)))[3].w; }
-        accepted += count; dropped += skip;
-        uint32_t rng = pcg4d16(slot, 0u, U.frame, P.seed); // :62
-        MCS mc_state = mc_load(F.mc, slot);
-        float sum = 0.0f, upd_T = 0.0f;
-        f3 pos = F3(0, 0, 0), normal = F3(0, 0, 0);
-        MCS new_state = {}; bool picked = false;
-        for (uint32_t k = 0; k < count; k++) { // arrival order = reverse chain order
-            const uint4* q = (const uint4*)(F.queue + chain[count - 1u - k]);
-            uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            f3 upos = F3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
-            f3 utgt = F3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
-            uint16_t mv[3] = {(uint16_t)(q3.x & 0xffffu), (uint16_t)(q3.x >> 16), (uint16_t)(q3.y & 0xffffu)};
-            if (k == 0) upd_T = __uint_as_float(q2.w);
-            MCS st = mc_state;
-            if (mc_state.id != q1.w) st = mc_state_new(rng);
-            mc_update(st, upos, __uint_as_float(q0.w), utgt, mv);
-            if (mc_state.id == st.id) mc_state = st;
-            sum += st.sum_w;
-            if (xorshift(rng) < st.sum_w / sum) { new_state = st; pos = upos; normal = F3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)); picked = true; }
-        }
-        new_state.T = upd_T;
-        if (picked) for (uint32_t k = 0; k < count; k++) { // :94-119
-            { uint32_t bi, h16; mc_static_buffer_index(P, rng, pos, bi, h16);
-              new_state.hash = h16; MCS old = mc_load(F.mc, bi);
-              if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
-            { uint32_t bi, h16; mc_adaptive_buffer_index(P, U, rng, pos, normal, bi, h16);
-              new_state.hash = h16; MCS old = mc_load(F.mc, bi);
-              if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
-        }
-        F.upd_head[slot] = 0u; // :121-122
-        F.upd_count[slot] = 0u;
+        accepted += apply_slot(P, F, slot, i);
     }
-    // statistics: accepted / dropped-by-cap updates of this frame
-    for (int off = 32; off > 0; off >>= 1) { accepted += __shfl_down(accepted, off, 64); dropped += __shfl_down(dropped, off, 64); }
-    if (F.count_stats && (threadIdx.x & 63) == 0) {
-        if (accepted) atomicAdd(&F.counters->mc_updates_accepted, (unsigned long long)accepted);
-        if (dropped) atomicAdd(&F.counters->mc_updates_dropped, (unsigned long long)dropped);
+    // statistics: updates applied this frame (those dropped by the cap are counted where they are dropped, at enqueue)
+    for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);
+    if (F.count_stats && (threadIdx.x & 63) == 0 && accepted) atomicAdd(&F.counters->mc_updates_accepted, (unsigned long long)accepted);
+}
+
+// The same pass in the reference's own dispatch order, serialised (property "debug: sequential update pass", a test
+// hook): compute_updates.comp runs one thread per slot of the whole table; here ONE lane walks the table's chain
+// heads in ascending slot order, so what a slot reads of the table is what all lower slots left -- deterministic, where
+// the parallel pass (like the reference's) lets slots that write the same cells race.
+__global__ __launch_bounds__(64) void mq_apply_seq_kernel(MqParams P, MqFrame F, uint32_t mc_total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t accepted = 0;
+    for (uint32_t base = 0; base < mc_total; base += 64u) {
+        const uint32_t s = base + (uint32_t)lane;
+        const uint32_t head = s < mc_total ? F.upd_head[s] : 0u;
+        unsigned long long m = __ballot(head != 0u);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1; m &= m - 1ull;
+            const uint32_t h = (uint32_t)__shfl((int)head, l, 64);
+            if (lane == 0) accepted += apply_slot(P, F, base + (uint32_t)l, h - 1u);
+        }
     }
+    if (F.count_stats && lane == 0 && accepted) atomicAdd(&F.counters->mc_updates_accepted, (unsigned long long)accepted);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1937,9 +1973,10 @@ int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, 
     else { if (count) mq_bounce_kernel<false, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); else mq_bounce_kernel<false, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); }
     return (int)hipGetLastError();
 }
-int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
+int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, uint32_t sequential_mc_total, hipStream_t s) {
     mq_link_kernel<<<grid, 256, 0, s>>>(F);
-    mq_apply_kernel<<<grid, 256, 0, s>>>(P, F);
+    if (sequential_mc_total) mq_apply_seq_kernel<<<1, 64, 0, s>>>(P, F, sequential_mc_total); // test hook: ascending slot order, one lane
+    else mq_apply_kernel<<<grid, 256, 0, s>>>(P, F);
     return (int)hipGetLastError();
 }
 int mq_launch_debug_view(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {

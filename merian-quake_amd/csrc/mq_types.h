@@ -114,7 +114,7 @@ struct MqUpdate {
     float normal[3];
     float T;
     uint16_t mv[3];
-    uint16_t rank;   // arrival rank within the slot (0..9)
+    uint16_t rank;   // arrival rank within the slot (0..9): the update pass replays a slot's entries in this order
     uint32_t slot;
     uint32_t next;   // index+1 of the previously pushed entry of this slot, 0 = end
 };
@@ -146,6 +146,7 @@ struct MqParams {
     int32_t enable_albedo_mipmap, enable_emission_mipmap; // g-buffer node, gbuffer.cpp:49-50,79-81
     int32_t debug_output_connected; // DEBUG_OUTPUT_CONNECTED, render_mcpg.cpp:182-183 (selector: debug_output_selector above)
     int32_t freeze_learning; // test hook: every learning computation and RNG draw runs, the stores to MC / LC / distance state do not
+    int32_t log_learning;    // test hook: every PROPOSED learning write is appended to MqFrame::learn_log (layouts: include/mq.h, mq_debug_learn_log_read)
     // derived on the host with the same float operations the kernels would use (mq_api.cpp props_to_params)
     float mc_static_inv_width;
     float mc_inv_width_lut[MQ_WIDTH_LUT]; // 1 / width(level) of the adaptive MC grid
@@ -226,6 +227,10 @@ struct MqFrame {
     uint32_t count_stats;  // != 0: kernels without a COUNT instantiation may bump `counters` too
     // traversal stack spill area: MQ_SPILL_ENTRIES 8-byte entries per resident lane
     unsigned long long* stack_spill;
+    // learning-write log (property "debug: log learning writes"): 64-byte records, count bumped per record
+    uint4* learn_log;
+    uint32_t* learn_log_count;
+    uint32_t learn_log_cap;
     // dynamic LDS of the shading kernels: 8-byte rows of 64 lanes per wave (lobe storage: 3 rows per Markov-chain sample)
     uint32_t lds_rows2;
 };

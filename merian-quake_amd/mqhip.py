@@ -124,6 +124,8 @@ def load_library(path=None):
         "mq_debug_state_read": (i32, [P, i32, vp, sz]),
         "mq_debug_state_write": (i32, [P, i32, vp, sz]),
         "mq_debug_section_clocks": (i32, [P, C.POINTER(C.c_uint64), i32, i32]),
+        "mq_debug_learn_log_read": (i32, [P, vp, sz, C.POINTER(sz)]),
+        "mq_debug_apply_updates": (i32, [P, vp, u32, C.POINTER(Uniform)]),
         "mq_set_partition": (i32, [P, i32, i32]),
         "mq_tiles_per_rank": (i32, [P, u32p, C.POINTER(sz)]),
         "mq_untile": (i32, [P, vp, vp]),
@@ -369,6 +371,20 @@ class Context:
     def state_write(self, which, a):
         a = np.ascontiguousarray(a, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE)[which])
         self._chk(self.lib.mq_debug_state_write(self.h, which, a.ctypes.data, a.nbytes))
+
+    def learn_log(self):
+        """Records of the last frame's learning-write log (property "debug: log learning writes"): (n, 16) uint32."""
+        n = C.c_size_t()
+        self._chk(self.lib.mq_debug_learn_log_read(self.h, None, 0, C.byref(n)))
+        a = np.zeros((n.value, 16), np.uint32)
+        if n.value:
+            self._chk(self.lib.mq_debug_learn_log_read(self.h, a.ctypes.data, n.value, C.byref(n)))
+        return a
+
+    def apply_updates(self, records, uniform):
+        """The update pass alone on caller-given queue contents: (n, 16) uint32 records with slot and rank filled in."""
+        r = np.ascontiguousarray(records, np.uint32).reshape(-1, 16)
+        self._chk(self.lib.mq_debug_apply_updates(self.h, r.ctypes.data, len(r), C.byref(uniform)))
 
     def section_clocks(self, reset=True):
         """-DMQ_PROF builds: shader clocks per code section (tools/prof_sections.py); zeros otherwise."""

@@ -103,6 +103,9 @@ struct orc_ctx {
     uint64_t iteration;
     orc_counters_t ctr;
     int racy; /* threads > 1 in guided mode */
+    /* learning-write log (params.log_learning) and the touch list of orc_debug_apply_updates */
+    uint32_t* llog; size_t llog_cap, llog_n;
+    uint32_t* touch; size_t touch_cap, touch_n;
 };
 
 /* ---------------------------------------------------------------- params */
@@ -122,7 +125,7 @@ void orc_params_header_defaults(orc_params_t* p) { /* render_mcpg.hpp:108-166, g
     p->volume_max_t = 1000.0f; p->surf_bsdf_p = 0.15f; p->volume_phase_p = 0.3f; p->dir_guide_prior = 0.2f; p->dist_guide_p = 0.0f;
     p->distance_mc_vertex_state_count = 10; p->seed = 0;
     { double d = 25.0; p->draine_g = (float)exp(-2.20679 / (d + 3.91029) - 0.428934); p->draine_a = (float)exp(3.62489 - 8.29288 / (d + 5.52825)); }
-    p->gbuffer_hide_sun = 1; p->quirk_lc_max_wo_p = 1; p->quirk_n16_wrap = 0; p->volume_forward_project = 1;
+    p->gbuffer_hide_sun = 1; p->quirk_lc_max_wo_p = 1; p->quirk_n16_wrap = 1; /* both on = what the reference's shaders compute (mcpg.comp:170; mc.glsl:26 with the uint16_t N of grid.h:19) */ p->volume_forward_project = 1;
     p->enable_albedo_mipmap = 1; p->enable_emission_mipmap = 1; /* src/gbuffer/gbuffer.hpp defaults; res/default_config.json:530-531 */
 }
 void orc_params_json_defaults(orc_params_t* p) { /* default_config.json:599-638 */
@@ -149,6 +152,7 @@ orc_ctx* orc_create(const orc_params_t* p) {
     return c;
 }
 static void free_state(orc_ctx* c) {
+    free(c->llog); c->llog = NULL; c->llog_cap = c->llog_n = 0;
     free(c->mc); free(c->lc); free(c->upd_count); free(c->upd_rec); free(c->upd_pool); free(c->upd_touched);
     free(c->irradiance); free(c->gb_albedo); free(c->gb_irr); free(c->gb_mv); free(c->gbuffer); free(c->hits);
     free(c->volume); free(c->volume_depth); free(c->prev_volume_depth); free(c->volume_mv); free(c->dist_mc); free(c->debug); c->debug = NULL;
@@ -543,6 +547,17 @@ typedef struct { const orc_ctx* c; orc_counters_t ctr; uint32_t rng; v3 sun_colo
 
 static inline v3 cam_x(const orc_ctx* c) { return V3(c->u.cam_x[0], c->u.cam_x[1], c->u.cam_x[2]); }
 
+/* learning-write log: one 16-dword record per proposed write (layouts: mq_oracle.h) */
+static void llog_append(orc_ctx* c, const uint32_t rec[16]) {
+    size_t at = __atomic_fetch_add(&c->llog_n, (size_t)1, __ATOMIC_RELAXED);
+    if (at < c->llog_cap) memcpy(c->llog + 16 * at, rec, 64);
+}
+static void llog_simple(orc_ctx* c, uint32_t kind, uint32_t index, uint32_t a, uint32_t b, uint32_t d, uint32_t e) {
+    uint32_t r[16]; memset(r, 0, sizeof r);
+    r[0] = a; r[1] = b; r[2] = d; r[3] = e; r[14] = index; r[15] = kind;
+    llog_append(c, r);
+}
+
 /* raytrace.glsl:25-60 */
 static v3 get_sky(const orc_ctx* c, v3 w, v3 sun_color) {
     v3 sun = V3(c->p.sun_w[0], c->p.sun_w[1], c->p.sun_w[2]);
@@ -825,8 +840,16 @@ static void mc_state_add_sample(tls_t* tl, const mcstate_t* st, v3 pos, float w,
     orc_ctx* c = (orc_ctx*)tl->c;
     uint32_t index = mc_buffer_index;
     if (index == 0xffffffffu) { uint16_t h; mc_adaptive_buffer_index(tl, pos, normal, &index, &h); }
+    uint32_t r[16];
+    r[0] = f2u(pos.x); r[1] = f2u(pos.y); r[2] = f2u(pos.z); r[3] = f2u(w);
+    r[4] = f2u(target.x); r[5] = f2u(target.y); r[6] = f2u(target.z); r[7] = st->id;
+    r[8] = f2u(normal.x); r[9] = f2u(normal.y); r[10] = f2u(normal.z); r[11] = f2u(c->u.cl_time);
+    r[12] = (uint32_t)orc_f2h(target_mv.x) | ((uint32_t)orc_f2h(target_mv.y) << 16); r[13] = (uint32_t)orc_f2h(target_mv.z);
+    r[14] = index; r[15] = 1u;
+    if (c->p.log_learning && c->p.freeze_learning) llog_append(c, r); /* proposed, never queued: no arrival rank */
     if (c->p.freeze_learning) return;
     uint32_t old = __atomic_fetch_add(&c->upd_count[index], 1u, __ATOMIC_RELAXED);
+    if (c->p.log_learning) { r[13] |= (old < 0xffffu ? old : 0xffffu) << 16; llog_append(c, r); } /* with the arrival rank (>= 10: dropped by the cap) */
     if (old >= MAX_UPDATES) { __atomic_fetch_sub(&c->upd_count[index], 1u, __ATOMIC_RELAXED); tl->ctr.mc_updates_dropped++; return; }
     uint32_t rec;
     if (old == 0) {
@@ -883,10 +906,22 @@ static void light_cache_update(tls_t* tl, v3 pos, v3 normal, v3 irr) {
     lc_address(tl, level, pos, normal, &idx, &chk);
     lcvertex_t* cell = &c->lc[idx];
     tl->ctr.lc_touches++;
-    if (c->p.freeze_learning) { /* every RNG draw of the update, none of its stores */
+    if (c->p.freeze_learning) { /* every RNG draw and computation of the update, none of its stores */
         if (c->u.frame == 0u) return; /* frame 0: the lock word (0) equals the frame number, the update is cancelled before any draw */
         lcvertex_t v = *cell;
-        if (v.hash != chk || h_bad(v.irr[0]) || h_bad(v.irr[1]) || h_bad(v.irr[2])) { v3 ci; uint16_t cn; light_cache_get_level(tl, &ci, &cn, level + 1, pos, normal); }
+        int rekey = v.hash != chk || h_bad(v.irr[0]) || h_bad(v.irr[1]) || h_bad(v.irr[2]);
+        if (rekey) {
+            v3 ci; uint16_t cn; light_cache_get_level(tl, &ci, &cn, level + 1, pos, normal);
+            v.irr[0] = orc_f2h(ci.x); v.irr[1] = orc_f2h(ci.y); v.irr[2] = orc_f2h(ci.z); v.N = cn;
+        }
+        if (c->p.log_learning) {
+            v.N = (uint16_t)(v.N + 1 < LIGHT_CACHE_MAX_N ? v.N + 1 : LIGHT_CACHE_MAX_N);
+            float a = omax(1.0f / (float)v.N, LIGHT_CACHE_MIN_ALPHA);
+            v3 cur = h3(v.irr);
+            llog_simple(c, 2u, idx, chk, (uint32_t)rekey,
+                        (uint32_t)orc_f2h(omix(cur.x, irr.x, a)) | ((uint32_t)orc_f2h(omix(cur.y, irr.y, a)) << 16),
+                        (uint32_t)orc_f2h(omix(cur.z, irr.z, a)) | ((uint32_t)v.N << 16));
+        }
         return;
     }
     uint32_t old = __atomic_exchange_n(&cell->lock, c->u.frame, __ATOMIC_ACQ_REL);
@@ -903,6 +938,7 @@ static void light_cache_update(tls_t* tl, v3 pos, v3 normal, v3 irr) {
     v3 cur = h3(v.irr);
     v.irr[0] = orc_f2h(omix(cur.x, irr.x, a)); v.irr[1] = orc_f2h(omix(cur.y, irr.y, a)); v.irr[2] = orc_f2h(omix(cur.z, irr.z, a));
     cell->hash = v.hash; cell->irr[0] = v.irr[0]; cell->irr[1] = v.irr[1]; cell->irr[2] = v.irr[2]; cell->N = v.N;
+    if (c->p.log_learning) llog_simple(c, 2u, idx, chk, 0u, (uint32_t)v.irr[0] | ((uint32_t)v.irr[1] << 16), (uint32_t)v.irr[2] | ((uint32_t)v.N << 16));
     __atomic_fetch_add(&cell->ok, 1u, __ATOMIC_RELAXED);
     __atomic_store_n(&cell->lock, 0u, __ATOMIC_RELEASE);
 }
@@ -1038,8 +1074,9 @@ static void mcpg_pixel(tls_t* tl, uint32_t px, uint32_t py) {
                     if (X(tl) * score_sum < mc_f * (float)p->mc_samples) {
                         v3 mv = orc_rh3(vscale(vsub(next.pos, next.prev_pos), 1.0f / c->u.cam_w[3]));
                         mc_state_add_sample(tl, &mc_state, cur.pos, mc_f, next.pos, mv, cur.normal, mc_buffer_index);
-                    } else if (p->mc_fast_recovery && !p->freeze_learning && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur.pos)) {
-                        c->mc[mc_buffer_index].sum_w = 0.0f; /* :177 */
+                    } else if (p->mc_fast_recovery && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur.pos)) {
+                        if (p->log_learning) llog_simple(c, 3u, mc_buffer_index, 0u, 0u, 0u, 0u);
+                        if (!p->freeze_learning) c->mc[mc_buffer_index].sum_w = 0.0f; /* :177 */
                     }
                 }
             }
@@ -1079,6 +1116,8 @@ static void apply_slot(tls_t* tl, uint32_t slot) {
     const mcupdate_t* up = &c->upd_pool[c->upd_rec[slot] - 1];
     tl->rng = orc_pcg4d16(slot, 0, c->u.frame, c->p.seed); /* :62 */
     mcstate_t mc_state = c->mc[slot];
+#define TOUCH(cell) do { if (c->touch) { if (c->touch_n < c->touch_cap) { c->touch[2 * c->touch_n] = slot; c->touch[2 * c->touch_n + 1] = (cell); } c->touch_n++; } } while (0)
+    TOUCH(slot);
     float sum = 0.0f; v3 pos = V3(0, 0, 0), normal = V3(0, 0, 0);
     mcstate_t new_state; memset(&new_state, 0, sizeof new_state); int picked = 0;
     for (uint32_t i = 0; i < count; i++) {
@@ -1091,14 +1130,15 @@ static void apply_slot(tls_t* tl, uint32_t slot) {
     }
     new_state.T = up->T;
     if (picked) for (uint32_t i = 0; i < count; i++) {
-        { uint32_t bi; uint16_t hash; mc_static_buffer_index(tl, pos, &bi, &hash);
+        { uint32_t bi; uint16_t hash; mc_static_buffer_index(tl, pos, &bi, &hash); TOUCH(bi);
           new_state.hash = hash; mcstate_t old = c->mc[bi];
           if (old.id == new_state.id || X(tl) < new_state.sum_w / (new_state.sum_w + old.sum_w)) c->mc[bi] = new_state; }
-        { uint32_t bi; uint16_t hash; mc_adaptive_buffer_index(tl, pos, normal, &bi, &hash);
+        { uint32_t bi; uint16_t hash; mc_adaptive_buffer_index(tl, pos, normal, &bi, &hash); TOUCH(bi);
           new_state.hash = hash; mcstate_t old = c->mc[bi];
           if (old.id == new_state.id || X(tl) < new_state.sum_w / (new_state.sum_w + old.sum_w)) c->mc[bi] = new_state; }
     }
     c->upd_count[slot] = 0; c->upd_rec[slot] = 0;
+#undef TOUCH
 }
 static int cmp_u32(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
 
@@ -1265,6 +1305,7 @@ static void volume_pixel(tls_t* tl, uint32_t px, uint32_t py) {
             if (s == p->volume_spp - 1) c->volume_depth[idx] = orc_f2h(dstate.sum_w > 0.0f ? dstate.m0 / dstate.sum_w : linear_z);
             if (X(tl) < l / (dist_score_sum / (float)p->distance_mc_samples)) { /* :213 */
                 uint32_t di = distance_mc_index(tl, (float)px, (float)py, grid_max_x);
+                if (p->log_learning) llog_simple(c, 4u, di, f2u(dstate.sum_w), dstate.N, f2u(dstate.m0), f2u(dstate.m1));
                 if (!p->freeze_learning) c->dist_mc[di] = dstate;
             }
             const float mc_f = orc_luminance(vscale(vscale(incident, phase), 1.0f / wo_p)); /* :218 */
@@ -1273,8 +1314,9 @@ static void volume_pixel(tls_t* tl, uint32_t px, uint32_t py) {
                 v3 jn = orc_sample_cos_frame(vneg(first_wi), x0, x1);
                 v3 mv = orc_rh3(vscale(vsub(next.pos, next.prev_pos), 1.0f / u->cam_w[3]));
                 mc_state_add_sample(tl, &mc_state, cur_pos, mc_f, next.pos, mv, jn, mc_buffer_index);
-            } else if (p->mc_fast_recovery && !p->freeze_learning && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur_pos)) {
-                c->mc[mc_buffer_index].sum_w = 0.0f;
+            } else if (p->mc_fast_recovery && mc_buffer_index != 0xffffffffu && mc_light_missing(p, &mc_state, mc_f, wo, cur_pos)) {
+                if (p->log_learning) llog_simple(c, 3u, mc_buffer_index, 0u, 0u, 0u, 0u);
+                if (!p->freeze_learning) c->mc[mc_buffer_index].sum_w = 0.0f; /* volume.comp:228 */
             }
         }
     }
@@ -1307,6 +1349,51 @@ static void run_pass(orc_ctx* c, int pass, int threads) {
     for (int i = 0; i < threads; i++) acc_ctr(&c->ctr, &jobs[i].ctr);
 }
 
+/* update pass, render_mcpg.cpp:270-277: every touched slot, ascending slot order */
+static void run_update_pass(orc_ctx* c) {
+    uint32_t n = c->upd_pool_used < c->upd_pool_cap ? c->upd_pool_used : c->upd_pool_cap;
+    qsort(c->upd_touched, n, 4, cmp_u32);
+    tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
+    for (uint32_t i = 0; i < n; i++) apply_slot(&tl, c->upd_touched[i]);
+    acc_ctr(&c->ctr, &tl.ctr);
+    c->upd_pool_used = 0;
+}
+
+const uint32_t* orc_learn_log(orc_ctx* c, size_t* n) { if (n) *n = c->llog_n; return c->llog; }
+int orc_learn_log_reset(orc_ctx* c, size_t capacity) {
+    if (capacity != c->llog_cap) { free(c->llog); c->llog = (uint32_t*)malloc((capacity ? capacity : 1) * 64); c->llog_cap = c->llog ? capacity : 0; }
+    c->llog_n = 0;
+    return c->llog ? 0 : -1;
+}
+
+int orc_debug_apply_updates(orc_ctx* c, const uint32_t* records, size_t n, const orc_uniform_t* u, uint32_t* touches, size_t touch_cap, size_t* n_touches) {
+    if (!c->mc || c->upd_pool_used != 0) return -1; /* needs a connected context with an empty queue */
+    c->u = *u;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t* r = records + 16 * i;
+        const uint32_t slot = r[14], rank = r[13] >> 16;
+        if (slot >= c->mc_total || rank >= MAX_UPDATES) return -2;
+        uint32_t rec;
+        if (c->upd_rec[slot] == 0) {
+            rec = c->upd_pool_used++;
+            if (rec >= c->upd_pool_cap) return -3;
+            c->upd_touched[rec] = slot; c->upd_rec[slot] = rec + 1;
+        } else rec = c->upd_rec[slot] - 1;
+        mcupdate_t* up = &c->upd_pool[rec];
+        if (rank == 0) up->T = u2f(r[11]);
+        up->positions[rank] = V3(u2f(r[0]), u2f(r[1]), u2f(r[2])); up->weights[rank] = u2f(r[3]);
+        up->targets[rank] = V3(u2f(r[4]), u2f(r[5]), u2f(r[6])); up->ids[rank] = r[7];
+        up->normals[rank] = V3(u2f(r[8]), u2f(r[9]), u2f(r[10]));
+        up->mv[rank][0] = (uint16_t)(r[12] & 0xffffu); up->mv[rank][1] = (uint16_t)(r[12] >> 16); up->mv[rank][2] = (uint16_t)(r[13] & 0xffffu);
+        c->upd_count[slot]++;
+    }
+    c->touch = touches; c->touch_cap = touches ? touch_cap : 0; c->touch_n = 0;
+    run_update_pass(c);
+    if (n_touches) *n_touches = c->touch_n;
+    c->touch = NULL; c->touch_cap = c->touch_n = 0;
+    return 0;
+}
+
 int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
     if (!c->irradiance) return -1;
     c->u = *u;
@@ -1318,13 +1405,7 @@ int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
     }
     run_pass(c, 0, threads);
     run_pass(c, 1, threads);
-    /* update pass, render_mcpg.cpp:270-277: every touched slot, ascending slot order */
-    uint32_t n = c->upd_pool_used < c->upd_pool_cap ? c->upd_pool_used : c->upd_pool_cap;
-    qsort(c->upd_touched, n, 4, cmp_u32);
-    tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
-    for (uint32_t i = 0; i < n; i++) apply_slot(&tl, c->upd_touched[i]);
-    acc_ctr(&c->ctr, &tl.ctr);
-    c->upd_pool_used = 0;
+    run_update_pass(c);
     /* volume passes, render_mcpg.cpp:280-320: copy mv, forward-project, single-scatter estimator.
      * Its Markov-chain updates stay queued until the next frame's update pass. */
     if (c->p.volume_spp > 0) {

@@ -94,6 +94,7 @@ typedef struct {
     int32_t enable_albedo_mipmap, enable_emission_mipmap; /* g-buffer node, src/gbuffer/gbuffer.cpp:49-50,79-81 */
     int32_t debug_output_connected, debug_output_selector; /* DEBUG_OUTPUT_CONNECTED / _SELECTOR, render_mcpg.cpp:172-173 */
     int32_t freeze_learning; /* test hook: learning computations and RNG draws run, the stores to MC / LC / distance state do not */
+    int32_t log_learning;    /* test hook: every PROPOSED learning write is appended to the learning log (orc_learn_log) */
 } orc_params_t;
 
 void orc_params_header_defaults(orc_params_t* p); /* src/render_mcpg/render_mcpg.hpp:108-166 */
@@ -150,6 +151,24 @@ void orc_get_counters(orc_ctx* c, orc_counters_t* out, int reset);
  * 2 = distance Markov chains (16 B: sum_w f32, N u32, m0 f32, m1 f32).
  * Returns a pointer into the context (valid until the next orc_connect) and the entry count. */
 void* orc_debug_state(orc_ctx* c, int which, size_t* count, size_t* entry_bytes);
+
+/* ---- learning-write log (test hook; the product library has the same log behind "debug: log learning writes") ----
+ * With params.log_learning set, every learning write a path PROPOSES is appended as one 64-byte record of 16 dwords
+ * (with freeze_learning also set nothing is stored, so the log is a deterministic function of the given state):
+ *   kind 1, a queued Markov-chain update (mc.glsl:159-184): the MqUpdate layout of the product's queue --
+ *           pos[3] weight target[3] id normal[3] T  mv0|mv1<<16  mv2|rank<<16 (rank 0 here)  slot  kind
+ *   kind 2, a light-cache store (light_cache.glsl:66-84): chk, rekeyed?, irr0|irr1<<16, irr2|N<<16, ... [14] = cell, [15] = kind
+ *   kind 3, a fast-recovery invalidation (mcpg.comp:175-178, volume.comp:226-229): [14] = slot, [15] = kind
+ *   kind 4, a distance-chain store (volume.comp:213-215): sum_w, N, m0, m1, ... [14] = index, [15] = kind
+ * orc_learn_log returns the records written since the last reset (count in *n); records beyond the capacity set by
+ * orc_learn_log_reset are counted but not kept. */
+const uint32_t* orc_learn_log(orc_ctx* c, size_t* n);
+int orc_learn_log_reset(orc_ctx* c, size_t capacity);
+/* Update application alone (compute_updates.comp:56-124) on caller-given queue contents: n records in the kind-1 layout
+ * above, each with its slot and its arrival rank (dense 0..k-1 per slot, k <= 10).  Slots are applied in ascending order.
+ * touches (may be NULL): receives up to touch_cap (slot, cell) pairs, one per table entry a slot's application reads or
+ * writes -- lets a test find slots whose applications interfere; *n_touches = pairs produced. */
+int orc_debug_apply_updates(orc_ctx* c, const uint32_t* records, size_t n, const orc_uniform_t* u, uint32_t* touches, size_t touch_cap, size_t* n_touches);
 
 /* closest-hit queries (raytrace.glsl:82-119 semantics: back-face cull, alpha any-hit, tmin 0,
  * tmax 1e4).  out_prim = (slot << 28 | prim) or 0xffffffff on miss. */

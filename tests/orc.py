@@ -32,7 +32,8 @@ class Params(C.Structure):
                 ("distance_mc_vertex_state_count", C.c_uint32), ("seed", C.c_uint32), ("gbuffer_hide_sun", C.c_int32),
                 ("quirk_lc_max_wo_p", C.c_int32), ("quirk_n16_wrap", C.c_int32), ("volume_forward_project", C.c_int32),
                 ("enable_albedo_mipmap", C.c_int32), ("enable_emission_mipmap", C.c_int32),
-                ("debug_output_connected", C.c_int32), ("debug_output_selector", C.c_int32), ("freeze_learning", C.c_int32)]
+                ("debug_output_connected", C.c_int32), ("debug_output_selector", C.c_int32), ("freeze_learning", C.c_int32),
+                ("log_learning", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -64,6 +65,10 @@ def lib():
         l.orc_math_eval.argtypes = [P, C.c_int, P, P, C.c_uint32]
         l.orc_debug_state.restype = C.c_void_p
         l.orc_debug_state.argtypes = [P, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        l.orc_learn_log.restype = C.c_void_p
+        l.orc_learn_log.argtypes = [P, C.POINTER(C.c_size_t)]
+        l.orc_learn_log_reset.argtypes = [P, C.c_size_t]
+        l.orc_debug_apply_updates.argtypes = [P, P, C.c_size_t, P, P, C.c_size_t, C.POINTER(C.c_size_t)]
         l.orc_params_header_defaults.argtypes = [C.POINTER(Params)]
         l.orc_params_json_defaults.argtypes = [C.POINTER(Params)]
         _lib = l
@@ -168,6 +173,29 @@ class Oracle:
         assert p and eb.value == dt.itemsize, (eb.value, dt.itemsize)
         return np.frombuffer((C.c_char * (n.value * eb.value)).from_address(p), dtype=dt)
 
+    def learn_log_reset(self, capacity):
+        assert self.l.orc_learn_log_reset(self.h, capacity) == 0
+
+    def learn_log(self):
+        """(n, 16) uint32 records of the learning-write log since the last reset (params.log_learning)."""
+        n = C.c_size_t()
+        p = self.l.orc_learn_log(self.h, C.byref(n))
+        if not n.value:
+            return np.zeros((0, 16), np.uint32)
+        return np.frombuffer((C.c_char * (n.value * 64)).from_address(p), dtype=np.uint32).copy().reshape(-1, 16)
+
+    def apply_updates(self, records, uniform, want_touches=False):
+        """compute_updates.comp alone on the given (n, 16) uint32 records; returns the (slot, cell) touch pairs if asked."""
+        r = np.ascontiguousarray(records, np.uint32).reshape(-1, 16)
+        cap = 32 * len(r) + 16 if want_touches else 0
+        t = np.zeros((cap, 2), np.uint32) if want_touches else None
+        nt = C.c_size_t()
+        rc = self.l.orc_debug_apply_updates(self.h, _ptr(r), len(r), C.addressof(uniform), _ptr(t), cap, C.byref(nt))
+        assert rc == 0, rc
+        if want_touches:
+            assert nt.value <= cap
+            return t[: nt.value]
+
     def math_eval(self, op, inp):
         inp = np.ascontiguousarray(inp, np.float32)
         n = inp.shape[0]
@@ -196,7 +224,7 @@ def params_from_ctx(ctx, constants=None):
     p.distance_mc_grid_width = int(g("dist mc grid width")); p.distance_mc_vertex_state_count = int(g("dist mc states per vertex"))
     p.volume_phase_p = g("Phase Prob"); p.dist_guide_p = g("dist guide p"); p.volume_forward_project = int(g("volume forward project"))
     p.enable_albedo_mipmap = int(g("enable albedo mipmap")); p.enable_emission_mipmap = int(g("enable emission mipmap"))
-    p.freeze_learning = int(g("debug: freeze learning"))
+    p.freeze_learning = int(g("debug: freeze learning")); p.log_learning = int(g("debug: log learning writes"))
     p.debug_output_connected = int(g("debug output connected")); p.debug_output_selector = int(g("debug output"))
     import math
     d = g("particle size")

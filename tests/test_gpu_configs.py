@@ -1,0 +1,104 @@
+"""The BASELINE.json configurations that rounds 1's suite left to a script: config 2 (id1 start.bsp stand-in,
+1280x720, unguided brute-force path tracing) and config 4 (ad_tears stand-in, 1920x1080, 4 spp MCPG + 4 spp
+single-scatter volumetrics, the frame tiled over 2 / 4 / 8 ranks) -- bit for bit against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+from test_gpu_parity import SMALL, VOL, _copy_learned_state, make_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TH = os.cpu_count() or 8
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx(mqlib):
+    import mqhip
+    ctx = mqhip.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def test_config2_start_1280x720_unguided(gpu_ctx):
+    """BASELINE config 2: synth_start(seed=1) 1280x720 1 spp, reference mode (pure BSDF sampling): the radiance image
+    and every g-buffer output bit-identical to the oracle, over two frames of the fly-through."""
+    import mqhip
+    ctx = gpu_ctx
+    o = make_pair(ctx, "synth_start", 1, {"reference mode": 1, "spp": 1, "max path length": 3}, 1280, 720)
+    for f in (0, 30):
+        u = ctx.synth_camera(f)
+        ctx.process(u); o.process(u, threads=TH)
+        img, ref = ctx.irradiance(), o.irradiance()
+        bad = (img.view(np.uint32) != ref.view(np.uint32)).any(-1)
+        assert not bad.any(), "frame %d: %d pixels differ, first %r" % (f, bad.sum(), np.argwhere(bad)[0])
+        l2 = np.sqrt(((img[..., :3] - ref[..., :3]) ** 2).sum(-1))
+        assert l2.max() < 1e-3  # north_star's bar (bit-identical implies it)
+        for g, r in ((mqhip.OUT_HITS, orc.OUT_HITS), (mqhip.OUT_GB_ALBEDO, orc.OUT_GB_ALBEDO), (mqhip.OUT_GB_IRRADIANCE, orc.OUT_GB_IRRADIANCE),
+                     (mqhip.OUT_GB_MV, orc.OUT_GB_MV), (mqhip.OUT_GBUFFER, orc.OUT_GBUFFER)):
+            assert np.array_equal(ctx.read_output(g), o.output(r)), "frame %d output %d" % (f, g)
+        assert ref[..., :3].sum() > 0
+
+
+C4 = {"reference mode": 0, "spp": 4, "max path length": 3, **VOL, "volume spp": 4, "volume forward project": 0, **SMALL}
+
+
+@pytest.fixture(scope="module")
+def config4_oracle(gpu_ctx):
+    """One oracle rendering of the config-4 frame from a given learning state, shared by the tiled cases."""
+    ctx = gpu_ctx
+    W, H = 1920, 1080
+    o = make_pair(ctx, "synth_tears", 3, C4, 160, 90)
+    for f in range(4):  # learning at a small size: the tables are addressed by world-space hash grids
+        o.process(ctx.synth_camera(36 + f), threads=1)
+    omc, olc = o.state(0).copy(), o.state(1).copy()
+    assert (omc["sum_w"] > 0).sum() > 1000
+    ctx.set_property("debug: freeze learning", 1)
+    try:
+        ctx.connect(W, H); o.connect(W, H)
+        o.set_params(orc.params_from_ctx(ctx, ctx.get_constants()))
+        u0, u1 = ctx.synth_camera(39), ctx.synth_camera(40)
+        o.process(u0, threads=TH)
+        o.state(0)[:] = omc; o.state(1)[:] = olc
+        dist = o.state(2)
+        rng = np.random.default_rng(4)  # distance chains are screen-space: give them a plausible learned content
+        dist["N"] = rng.integers(1, 200, len(dist)); dist["sum_w"] = rng.random(len(dist), dtype=np.float32) * 0.2
+        mean = rng.random(len(dist), dtype=np.float32) * 600 + 20
+        dist["m0"] = dist["sum_w"] * mean; dist["m1"] = dist["sum_w"] * (mean * mean + rng.random(len(dist), dtype=np.float32) * 400)
+        dstate = dist.copy()
+        o.process(u1, threads=TH)
+        yield o, (u0, u1), dstate
+    finally:
+        ctx.set_property("debug: freeze learning", 0)
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (2, 1), (4, 2), (8, 5)])
+def test_config4_tears_4spp_volume_tiled(gpu_ctx, config4_oracle, world, rank):
+    """BASELINE config 4: synth_tears(seed=3) 1920x1080, 4 spp guided surface estimator + 4 spp guided single-scatter
+    volume estimator in fog, rendered as rank `rank` of a `world`-way tile partition: the rank's `irradiance` and
+    `volume` tile buffers (what the all-gather moves) are bit-identical to the same tiles of the oracle's frame."""
+    import mqhip
+    sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
+    import mq_tiles
+    ctx = gpu_ctx
+    o, (u0, u1), dstate = config4_oracle
+    W, H = 1920, 1080
+    ctx.set_property("debug: freeze learning", 1)
+    try:
+        ctx.set_partition(rank, world); ctx.connect(W, H)
+        ctx.process(u0)  # the first frame after a connect zeroes the tables
+        _copy_learned_state(ctx, o)  # the oracle's tables are unchanged by its frozen frames
+        ctx.state_write(2, dstate)
+        ctx.process(u1)
+        for name, which, ref in (("irradiance", mqhip.OUT_TILES, o.irradiance()), ("volume", mqhip.OUT_VOLUME_TILES, o.volume())):
+            got = ctx.read_output(which).view(np.float32).reshape(-1, 64, 4)
+            want = mq_tiles.tile_image(ref, rank, world)
+            bad = (got.view(np.uint32) != want.view(np.uint32)).any(-1)
+            assert not bad.any(), "%s, rank %d of %d: %d pixels differ, first %r" % (name, rank, world, bad.sum(), np.argwhere(bad)[0])
+            assert want[..., :3].sum() > 0
+    finally:
+        ctx.set_property("debug: freeze learning", 0)
+        ctx.set_partition(0, 1)

@@ -62,3 +62,48 @@ def test_partition_covers_every_tile_once():
             sizes = [len(mq_tiles.local_tiles(W, H, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1 and max(sizes) == mq_tiles.tiles_per_rank(W, H, world)
     assert mq_tiles.tiles_per_rank(1920, 1080, 8) * 64 * 16 == 4147200  # 4.15 MB per rank at 1080p / 8 GPUs
+
+
+def test_bench_gpus_n_launches_n_ranks_itself(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher around it starts N ranks with torch.distributed.run (rendezvous on
+    127.0.0.1), relays rank 0's result line and insists that the line reports N ranks."""
+    import importlib
+    import json
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        class R:
+            returncode = 0
+        R.stdout = "noise from a rank\n" + json.dumps({"metric": "m", "n_gpus": seen["n"]}) + "\n"
+        return R
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    seen["n"] = 4
+    bench.main()
+    out = capsys.readouterr()
+    assert json.loads(out.out.strip())["n_gpus"] == 4 and "noise" in out.err
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen["n"] = 1  # a run that silently rendered on one rank must not pass for a 4-rank result
+    with pytest.raises(SystemExit):
+        bench.main()
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """On this GPU-less box every rank stops with "needs a HIP device": the launcher must turn that into its own
+    failure (and must get that far without touching a GPU itself)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run")
+    assert r.returncode != 0 and '{"metric"' not in r.stdout
+    assert "2-rank run failed" in r.stderr

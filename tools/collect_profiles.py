@@ -14,6 +14,18 @@ import glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise
 
+def per_dispatch(d, counter):
+    """{kernel: [counter value per dispatch, in dispatch order]} of one rocprofv3 counter pass"""
+    import csv
+    out = {}
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
+            out.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), []).append(float(r["Counter_Value"]))
+    return out
+
+
 def main(tag):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
@@ -28,6 +40,22 @@ def main(tag):
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch"] = 1024.0 * (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"])
             v["hbm_read_bytes_per_launch"] = 1024.0 * 2.0 * v["FETCH_SIZE"]["mean"]
+    # per frame of the run (dispatch order = frame order): bench.py reports `traffic` over exactly its own timed frames
+    bench = json.loads([l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1])
+    n_frames = bench.get("learning_frames", bench["warmup"]) + bench["steps"]
+    fetch, write = per_dispatch(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), per_dispatch(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    for kn, v in pmc.items():
+        f, w = fetch.get(kn), write.get(kn)
+        if not f or not w or len(f) != len(w) or "true>" in kn.split(",")[-1] or not kn.startswith("mq_"):
+            continue
+        k = len(f) // n_frames
+        if k == 0 or k * n_frames > len(f):
+            continue
+        f, w = f[:k * n_frames], w[:k * n_frames]  # the counting frames after the timed region use other instantiations
+        v["launches_per_frame"] = k
+        v["hbm_bytes_per_frame"] = [round(1024.0 * sum(2.0 * a + b for a, b in zip(f[i * k:(i + 1) * k], w[i * k:(i + 1) * k]))) for i in range(n_frames)]
+    pmc["_run"] = {"workload": "default", "steps": bench["steps"], "warmup": bench["warmup"], "learning_frames": bench.get("learning_frames", bench["warmup"]),
+                   "command": "python3 bench.py --no-cpu-baseline (tools/profile_round.sh)"}
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
     for name in ("bench_under_rocprof.json", "bench.json"):
         lines = [l for l in open(os.path.join(src, name)) if l.startswith("{")]
@@ -37,7 +65,7 @@ def main(tag):
     traces = glob.glob(src + "/trace/**/*kernel_trace.csv", recursive=True)
     if traces:
         bench = json.loads([l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1])
-        steps, warm = bench["steps"], bench["warmup"]
+        steps, warm = bench["steps"], bench.get("learning_frames", bench["warmup"])
         per = {}
         for r in csv.DictReader(open(traces[0])):
             n = r["Kernel_Name"]
