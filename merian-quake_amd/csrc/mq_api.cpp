@@ -111,6 +111,25 @@ struct mq_ctx {
     bool ev_detail[EV_RING] = {};     // the slot's frame recorded the per-launch events
     uint32_t ev_counter = 0, t_detail_frames = 0, timing_interval = 1;
     hipStream_t last_stream = nullptr;
+    // sub-pipelines (property "pipelines"): the rank's pixel slots are cut into `subs` contiguous ranges, each rendered by
+    // its own chain of launches on its own stream (sub 0 on the caller's); they join before the update pass
+    static const int MAX_SUBS = 4;
+    int subs = 1;                         // in effect since the last connect
+    uint32_t sub_slot_begin[MAX_SUBS + 1] = {};
+    uint32_t sub_ray_cap = 0;             // queue positions per sub-pipeline (ray_cap = subs * sub_ray_cap)
+    hipStream_t side[MAX_SUBS - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SUBS - 1] = {};
+    // camera rays of the NEXT frame beside the kernels of this one (property "overlap camera rays"): they depend on the
+    // scene and the camera only.  Traced on pt_stream into the hit buffer of the frame's parity; ev_pt_done[p]: traced,
+    // ev_shaded[p]: the first-hit kernel that read buffer p has finished (the buffer may be overwritten).
+    hipStream_t pt_stream = nullptr;
+    DevBuf d_prim_hits[2];
+    hipEvent_t ev_pt_done[2] = {}, ev_shaded[2] = {};
+    bool shaded_valid[2] = {false, false};
+    uint32_t frame_parity = 0;
+    hipEvent_t ev_pt_t[EV_RING][2] = {}; // start / end of the camera-ray launch on pt_stream (frames with per-launch events)
+    bool ev_pt_timed[EV_RING] = {};
+    double t_pt_kernel_sum = 0.0;
     mq_ctx() : tex(MQ_MAX_GLTEXTURES) {}
 };
 
@@ -204,6 +223,9 @@ const PropDesc k_props[] = {
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
+    // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
+    {"pipelines", PT_INT, POFF(pipelines), true, {}},
+    {"overlap camera rays", PT_BOOL, POFF(overlap_camera_rays), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
     {"quirk: 16-bit N*N", PT_BOOL, POFF(quirk_n16_wrap), false, {}},
@@ -324,6 +346,7 @@ void free_frame_state(mq_ctx* c) {
     dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
     dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0;
+    dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); c->shaded_valid[0] = c->shaded_valid[1] = false;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
@@ -388,6 +411,13 @@ int mq_create(mq_ctx** out, int device) {
         c->cu_count = prop.multiProcessorCount;
         c->device = device;
         for (auto& tr : c->evr) for (auto& e3 : tr) if (hipEventCreate(&e3) != hipSuccess) { delete c; return MQ_EHIP; }
+        bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; ok && k < mq_ctx::MAX_SUBS - 1; k++)
+            ok = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&c->pt_stream, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; ok && k < 2; k++) ok = hipEventCreateWithFlags(&c->ev_pt_done[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_shaded[k], hipEventDisableTiming) == hipSuccess;
+        for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) ok = ok && hipEventCreate(&e4) == hipSuccess;
+        if (!ok) { delete c; return MQ_EHIP; }
     }
     *out = c;
     return MQ_OK;
@@ -400,6 +430,11 @@ void mq_destroy(mq_ctx* c) {
         (void)hipDeviceSynchronize();
         free_frame_state(c); free_scene_dev(c);
         for (auto& tr : c->evr) for (auto& e : tr) if (e) (void)hipEventDestroy(e);
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->pt_stream) (void)hipStreamDestroy(c->pt_stream);
+        for (int k = 0; k < 2; k++) { if (c->ev_pt_done[k]) (void)hipEventDestroy(c->ev_pt_done[k]); if (c->ev_shaded[k]) (void)hipEventDestroy(c->ev_shaded[k]); }
+        for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) if (e4) (void)hipEventDestroy(e4);
+        for (int k = 0; k < mq_ctx::MAX_SUBS - 1; k++) { if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); if (c->side[k]) (void)hipStreamDestroy(c->side[k]); }
     }
     delete c;
 }
@@ -773,15 +808,22 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_upd_head, (size_t)c->mc_total * 4))) return r;
     c->queue_cap = (uint32_t)std::min<size_t>(queue_entries_needed(c), 0x7fffffffu);
     if ((r = dev_alloc(c, c->d_queue, (size_t)c->queue_cap * sizeof(MqUpdate)))) return r;
-    if ((r = dev_alloc(c, c->d_ctrl, MQ_CTRL_WORDS * 4))) return r;
+    c->subs = std::min(std::max(1, c->props.pipelines), (int)mq_ctx::MAX_SUBS);
+    if ((r = dev_alloc(c, c->d_ctrl, (size_t)c->subs * MQ_CTRL_WORDS * 4))) return r; // block 0: the rank's (flags, update tails) + sub 0's queues; block k: sub k's queues
     if ((r = dev_alloc(c, c->d_counters, sizeof(MqCountersDev)))) return r;
     HIPCHK(c, hipMemset(c->d_counters.p, 0, sizeof(MqCountersDev)));
     c->grid_blocks = std::max(1, c->cu_count) * 8;
-    if ((r = dev_alloc(c, c->d_spill, (size_t)c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
+    if ((r = dev_alloc(c, c->d_spill, (size_t)c->subs * c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r; // one region per sub-pipeline
     const size_t slots = (size_t)c->tiles_per_rank * 64;
     if ((r = dev_alloc(c, c->d_paths, slots * 112))) return r; // 7 fields of 16 bytes (the volume pass uses 6)
     if ((r = dev_alloc(c, c->d_debug_rng, (size_t)c->W * c->H * 4))) return r;
-    c->ray_cap = (uint32_t)(2 * slots + 1024); // sharded queues interleave 16 tails: room for shard imbalance
+    for (int k = 0; k < 2; k++) if ((r = dev_alloc(c, c->d_prim_hits[k], slots * 16))) return r;
+    // sub-pipeline k renders the local tiles [n * k / subs, n * (k + 1) / subs); its queues hold 2x its pixel slots + 1024
+    // positions (sharded queues interleave 16 tails: room for shard imbalance).  The regions are consecutive parts of the
+    // same allocations, so a launch over the whole rank (the volume pass) uses them as ONE queue of ray_cap positions.
+    for (int k = 0; k <= c->subs; k++) c->sub_slot_begin[k] = (uint32_t)((uint64_t)c->n_local_tiles * k / c->subs) * 64u;
+    c->sub_ray_cap = (uint32_t)(2 * ((slots / 64 + c->subs - 1) / c->subs + 1) * 64 + 1024);
+    c->ray_cap = c->sub_ray_cap * (uint32_t)c->subs;
     if ((r = dev_alloc(c, c->d_rays, (size_t)c->ray_cap * 32 * 2))) return r; // two buffers, by round parity (ray_buffer in the kernels)
     if ((r = dev_alloc(c, c->d_ray_hits, (size_t)c->ray_cap * 16))) return r;
     if ((r = dev_alloc(c, c->d_qslots[0], (size_t)c->ray_cap * 4))) return r;
@@ -811,7 +853,11 @@ static int drain_slot(mq_ctx* c, int slot) {
     float ptrace = 0;
     HIPCHK(c, hipEventElapsedTime(&ptrace, c->evr[slot][0], c->evr[slot][1])); // mq_primary_trace_kernel (~0 in a counting frame: traced inline)
     HIPCHK(c, hipEventElapsedTime(&prim, c->evr[slot][1], c->evr[slot][2]));
-    c->t_round_trace[0] += ptrace; c->t_round_shade[0] += prim;
+    if (c->ev_pt_timed[slot]) { // traced on its own stream beside the previous frame: the launch's own duration; ev[0] -> ev[1] above is what the frame waited for it
+        float k = 0; HIPCHK(c, hipEventElapsedTime(&k, c->ev_pt_t[slot][0], c->ev_pt_t[slot][1]));
+        c->t_round_trace[0] += k; c->t_pt_kernel_sum += k;
+    } else c->t_round_trace[0] += ptrace;
+    c->t_round_shade[0] += prim;
     prim += ptrace; // "primary" = both launches of the first hit; "trace" = the queue kernel of the bounce rounds only
     for (int k = 0; k < R; k++) {
         HIPCHK(c, hipEventElapsedTime(&x, c->evr[slot][2 + 2 * k], c->evr[slot][3 + 2 * k])); tr += x; c->t_round_trace[1 + k] += x;
@@ -827,7 +873,8 @@ static int drain_slot(mq_ctx* c, int slot) {
 
 int mq_reset_state(mq_ctx* c) { if (!c) return MQ_EINVAL; c->iteration = 0; return MQ_OK; }
 
-static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
+// sub < 0: a launch over the whole rank (all queue regions as one); sub >= 0: sub-pipeline `sub`
+static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1) {
     memset(&F, 0, sizeof F);
     F.u = *u; F.W = c->W; F.H = c->H; F.tiles_x = c->tiles_x; F.tiles_y = c->tiles_y;
     F.n_local_tiles = c->n_local_tiles; F.rank = (uint32_t)c->rank; F.world = (uint32_t)c->world;
@@ -837,9 +884,15 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F) {
     F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
     F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.counters = (MqCountersDev*)c->d_counters.p; F.count_stats = c->count_enabled ? 1u : 0u;
-    F.stack_spill = (unsigned long long*)c->d_spill.p;
-    F.paths = (uint4*)c->d_paths.p; F.n_slots = c->tiles_per_rank * 64u; F.rays = (float4*)c->d_rays.p; F.ray_hits = (uint4*)c->d_ray_hits.p;
-    F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p; F.ray_cap = c->ray_cap;
+    const size_t k = sub < 0 ? 0 : (size_t)sub, qoff = k * c->sub_ray_cap;
+    F.slot_begin = sub < 0 ? 0u : c->sub_slot_begin[sub]; F.slot_end = sub < 0 ? c->n_local_tiles * 64u : c->sub_slot_begin[sub + 1];
+    F.qctrl = F.ctrl + k * MQ_CTRL_WORDS;
+    F.stack_spill = (unsigned long long*)c->d_spill.p + k * c->grid_blocks * mq_render_block_size() * mq_spill_entries();
+    F.paths = (uint4*)c->d_paths.p; F.n_slots = c->tiles_per_rank * 64u;
+    F.rays = (float4*)c->d_rays.p + 4 * qoff; F.ray_hits = (uint4*)c->d_ray_hits.p + qoff; // rays: two buffers (round parity) of origins + directions per region
+    F.prim_hits = (uint4*)c->d_prim_hits[c->frame_parity & 1].p;
+    F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p + qoff; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p + qoff;
+    F.ray_cap = sub < 0 ? c->ray_cap : c->sub_ray_cap;
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
     F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
     F.learn_log = (uint4*)c->d_learn_log.p; F.learn_log_count = (uint32_t*)c->d_learn_count.p; F.learn_log_cap = c->learn_log_cap;
@@ -919,7 +972,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         HIPCHK(c, hipMemsetAsync(c->d_upd_count.p, 0, c->d_upd_count.bytes, s));
         HIPCHK(c, hipMemsetAsync(c->d_upd_head.p, 0, c->d_upd_head.bytes, s));
         HIPCHK(c, hipMemsetAsync(c->d_dist_mc.p, 0, c->d_dist_mc.bytes, s)); // volume_distancemc, render_mcpg.cpp:225
-        HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, MQ_CTRL_WORDS * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->d_ctrl.p, 0, c->d_ctrl.bytes, s));
     }
     const bool first_iteration = c->iteration == 0;
     c->iteration++;
@@ -928,7 +981,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
         return MQ_OK;
     }
-    HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_QUEUE0, 0, (MQ_CTRL_WORDS - MQ_CTRL_QUEUE0) * 4, s)); // queue counters; the update tail survives (volume-pass entries of the last frame)
+    HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_QUEUE0, 0, ((size_t)c->subs * MQ_CTRL_WORDS - MQ_CTRL_QUEUE0) * 4, s)); // queue counters of every sub-pipeline; the update tail survives (volume-pass entries of the last frame)
     if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, offsetof(MqCountersDev, prof), s));
     const bool guided = !c->params.reference_mode;
     // rounds: every sample needs at most (max_path_length - 1) traced segments, render_mcpg.cpp:142-143
@@ -943,20 +996,63 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     c->ev_detail[slot] = detail;
     HIPCHK(c, hipEventRecord(ev[0], s));
     int e = 0;
-    if (!c->count_enabled) { // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
-        e = mq_launch_primary_trace(c->scene, c->params, F, c->grid_frame[1], s);
-        if (e) return fail(c, MQ_EHIP, std::string("primary trace launch: ") + hipGetErrorString((hipError_t)e));
+    // ---- surface pass: `subs` independent chains of launches (each over its own pixel slots, with its own queues) on
+    // `subs` streams.  A launch of this pipeline ends with the tail of its longest ray or path on a nearly idle chip;
+    // with several chains in flight the tail of one overlaps the body of another.  Chain 0 runs on the caller's stream
+    // (and carries the per-launch timing events), the others fork from it here and join it before the update pass.
+    const int S = c->subs;
+    MqFrame FS[mq_ctx::MAX_SUBS];
+    for (int k = 0; k < S; k++) fill_frame(c, u, FS[k], k);
+    auto st = [&](int k) { return k == 0 ? s : c->side[k - 1]; };
+    auto sub_grid = [&](int i) { return std::max(std::max(1, c->cu_count), c->grid_frame[i] / S); }; // the chains share the chip
+    if (S > 1) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, s));
+        for (int k = 1; k < S; k++) HIPCHK(c, hipStreamWaitEvent(st(k), c->ev_fork, 0));
+    }
+    // The camera rays of this frame do not wait for the previous frame: the host runs ahead of the device, so this
+    // launch executes beside the previous frame's kernels and fills the tails of their launches.  It waits only for
+    // the first-hit kernel that last read the hit buffer of this parity (two frames ago).
+    const bool overlap_pt = c->props.overlap_camera_rays && !c->count_enabled;
+    const uint32_t parity = c->frame_parity & 1u;
+    c->ev_pt_timed[slot] = overlap_pt && detail;
+    if (overlap_pt) {
+        if (c->shaded_valid[parity]) HIPCHK(c, hipStreamWaitEvent(c->pt_stream, c->ev_shaded[parity], 0));
+        if (detail) HIPCHK(c, hipEventRecord(c->ev_pt_t[slot][0], c->pt_stream));
+    }
+    auto join = [&]() -> int {
+        for (int k = 1; k < S; k++) { HIPCHK(c, hipEventRecord(c->ev_join[k - 1], st(k))); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0)); }
+        return MQ_OK;
+    };
+    if (!c->count_enabled) // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
+        for (int k = 0; k < S; k++) {
+            e = mq_launch_primary_trace(c->scene, c->params, FS[k], overlap_pt ? c->grid_frame[1] : sub_grid(1), overlap_pt ? c->pt_stream : st(k));
+            if (e) return fail(c, MQ_EHIP, std::string("primary trace launch: ") + hipGetErrorString((hipError_t)e));
+        }
+    if (overlap_pt) {
+        if (detail) HIPCHK(c, hipEventRecord(c->ev_pt_t[slot][1], c->pt_stream));
+        HIPCHK(c, hipEventRecord(c->ev_pt_done[parity], c->pt_stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_pt_done[parity], 0));
+        for (int k = 1; k < S; k++) HIPCHK(c, hipStreamWaitEvent(st(k), c->ev_pt_done[parity], 0));
     }
     if (detail) HIPCHK(c, hipEventRecord(ev[1], s));
-    e = mq_launch_primary(c->scene, c->params, F, guided, c->count_enabled, c->grid_frame[0], s);
-    if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
+    for (int k = 0; k < S; k++) {
+        e = mq_launch_primary(c->scene, c->params, FS[k], guided, c->count_enabled, sub_grid(0), st(k));
+        if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    if (rounds == 0 || (overlap_pt && S > 1)) { int r = join(); if (r) return r; } // (every chain's first-hit kernel must be done before ev_shaded)
+    if (overlap_pt) { HIPCHK(c, hipEventRecord(c->ev_shaded[parity], s)); c->shaded_valid[parity] = true; }
     if (detail || timed == 0) HIPCHK(c, hipEventRecord(ev[2], s));
     for (int r = 0; r < rounds; r++) {
-        e = mq_launch_trace_queue(c->scene, F, r, c->count_enabled, c->grid_frame[1], s);
-        if (e) return fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e));
+        for (int k = 0; k < S; k++) {
+            e = mq_launch_trace_queue(c->scene, FS[k], r, c->count_enabled, sub_grid(1), st(k));
+            if (e) return fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e));
+        }
         if (r < timed && detail) HIPCHK(c, hipEventRecord(ev[3 + 2 * r], s));
-        e = mq_launch_bounce(c->scene, c->params, F, r, guided, c->count_enabled, c->grid_frame[2], s);
-        if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
+        for (int k = 0; k < S; k++) {
+            e = mq_launch_bounce(c->scene, c->params, FS[k], r, guided, c->count_enabled, sub_grid(2), st(k));
+            if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
+        }
+        if (r == rounds - 1) { int rr = join(); if (rr) return rr; } // every chain is done before the render interval ends
         if (r < timed && (detail || r == timed - 1)) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s)); // the last one ends the render interval
     }
     if (c->params.debug_output_connected) { // mcpg.comp:212-277: part of the surface pass, i.e. before the update pass
@@ -993,6 +1089,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         c->volume_outputs_zero = true;
     }
     HIPCHK(c, hipEventRecord(ev[3 + 2 * timed], s));
+    c->frame_parity++;
     c->ev_rounds[slot] = timed;
     c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
     c->ev_valid = true;
@@ -1035,7 +1132,7 @@ int mq_timing_reset(mq_ctx* c) {
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
     for (int i = 0; i < mq_ctx::EV_RING; i++) { int r = drain_slot(c, i); if (r) return r; }
     c->t_render_sum = c->t_update_sum = 0.0; c->t_frames = 0; c->t_detail_frames = 0; c->ev_counter = 0;
-    c->t_primary_sum = c->t_trace_sum = c->t_bounce_sum = 0.0;
+    c->t_primary_sum = c->t_trace_sum = c->t_bounce_sum = 0.0; c->t_pt_kernel_sum = 0.0;
     for (int i = 0; i < MQ_TIMING_ROUNDS; i++) c->t_round_trace[i] = c->t_round_shade[i] = 0.0;
     return MQ_OK;
 }

@@ -73,6 +73,8 @@ struct MqProps {
     bool debug_output_connected = false; // the reference derives this from the graph wiring (render_mcpg.cpp:182-183)
     bool freeze_learning = false; // test hook, not a reference property
     bool log_learning = false;    // test hook, not a reference property
+    bool overlap_camera_rays = false; // scheduling of this build: the camera rays of frame n + 1 traced beside the kernels of frame n (measured: no gain)
+    int pipelines = 1; // scheduling of this build, not a reference property: sub-pipelines per frame (mq_api.cpp mq_process)
     bool sequential_update_pass = false; // test hook: the update pass in the reference's dispatch order, one slot after the other
     // named quirk switches: on = what the reference's shaders compute, off = the evident intent
     bool quirk_lc_max_wo_p = true; // mcpg.comp:170 `max(wo_p, 10)`

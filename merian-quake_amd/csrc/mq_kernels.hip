@@ -968,7 +968,7 @@ MQ_DEV uint32_t shard_append(uint32_t* tails, bool push) { // returns the interl
     return pos;
 }
 MQ_DEV uint32_t queue_append(const MqFrame& F, int round, bool& push) {
-    uint32_t q = shard_append(F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP, push);
+    uint32_t q = shard_append(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP, push);
     if (push && q >= F.ray_cap) { atomicOr(&F.ctrl[0], 1u); push = false; } // cannot happen with the 2x margin; flagged, never silent
     return q;
 }
@@ -989,7 +989,7 @@ MQ_DEV void emit_ray(const MqFrame& F, int round, uint32_t q, uint32_t slot, con
 
 // ---- camera rays: traversal alone, at the register budget of the traversal kernel (76 VGPRs, 6 waves/SIMD; inside
 // the first-hit shading kernel the same loop ran at 3 waves/SIMD), one 8x8 tile per wave so that its rays stay coherent
-// to the end.  The closest hits go to ray_hits[pixel slot] for mq_primary_kernel to shade (16 B written + read per
+// to the end.  The closest hits go to prim_hits[pixel slot] for mq_primary_kernel to shade (16 B written + read per
 // pixel and one more launch: 0.647 -> 0.619 ms for both kernels together at 1920x1080).
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_primary_trace_kernel(MqSceneDev sc, MqFrame F, float fov_tan_alpha_half) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
@@ -997,17 +997,17 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_primary_trace_kerne
     uint2* stk = &s_stack[threadIdx.x >> 6][0][lane];
     unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * MQ_BLOCK + threadIdx.x) * MQ_SPILL_ENTRIES;
     const mq_uniform& U = F.u;
-    const uint32_t total = F.n_local_tiles * 64u;
+    const uint32_t total = F.slot_end; // this pipeline's pixel slots: [slot_begin, slot_end)
     const float Wf = (float)F.W, Hf = (float)F.H;
     Ctr ctr = {};
-    for (uint32_t my = blockIdx.x * MQ_BLOCK + threadIdx.x; my < total; my += gridDim.x * MQ_BLOCK) {
+    for (uint32_t my = F.slot_begin + blockIdx.x * MQ_BLOCK + threadIdx.x; my < total; my += gridDim.x * MQ_BLOCK) {
         const uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
         const uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
         if (px >= F.W || py >= F.H) continue;
         const f3 up = F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), fw = F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]);
         RayHit rhit;
         traverse<false>(sc, cam_pos(U), camera_ray_dir((float)px, (float)py, Wf, Hf, up, fw, fov_tan_alpha_half), rhit, stk, spill, ctr);
-        F.ray_hits[my] = make_uint4(rhit.tri, __float_as_uint(rhit.t), __float_as_uint(rhit.u), __float_as_uint(rhit.v));
+        F.prim_hits[my] = make_uint4(rhit.tri, __float_as_uint(rhit.t), __float_as_uint(rhit.u), __float_as_uint(rhit.v));
     }
 }
 
@@ -1023,16 +1023,16 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
     uint2* stk = s_dyn + (size_t)wave * F.lds_rows2 * 64 + lane;
     float* lobes = GUIDED ? (float*)(s_dyn + (size_t)wave * F.lds_rows2 * 64) + lane : nullptr;
     unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * MQ_BLOCK + threadIdx.x) * MQ_SPILL_ENTRIES;
-    const uint32_t total = F.n_local_tiles * 64u;
+    const uint32_t total = F.slot_end; // this pipeline's pixel slots: [slot_begin, slot_end)
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
     const f3 gb_sun = P.gbuffer_hide_sun ? F3(0.0f, 0.0f, 0.0f) : F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
     const uint32_t stride = gridDim.x * MQ_BLOCK;
-    const uint32_t rounds = (total + stride - 1) / stride;
+    const uint32_t rounds = (total - F.slot_begin + stride - 1) / stride;
     PSTART(ctr);
     for (uint32_t it = 0; it < rounds; it++) {
-        const uint32_t my = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        const uint32_t my = F.slot_begin + it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
         bool cont = false;
         Path p = {};
         PLAP(ctr, 0);
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 f3 ro = cam_pos(U);
                 f3 rd = camera_ray_dir((float)p.px, (float)p.py, Wf, Hf, up, fw, P.fov_tan_alpha_half);
                 RayHit rhit;
-                if constexpr (!COUNT) { const uint4 hq = F.ray_hits[my]; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w); } // traced by mq_primary_trace_kernel
+                if constexpr (!COUNT) { const uint4 hq = F.prim_hits[my]; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w); } // traced by mq_primary_trace_kernel
                 else traverse<COUNT>(sc, ro, rd, rhit, stk, spill, ctr); // the counting instantiation traces inline: its counters price the camera rays
                 PLAP(ctr, 1);
                 Hit h; h.pos = ro; h.wi = rd; h.prev_pos = ro; h.normal = F3(0, 0, 1); h.enc_geonormal = 0; h.albedo = F3(0, 0, 0); h.roughness = 0.0f;
@@ -1134,8 +1134,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     uint2* stk = &s_stack[threadIdx.x >> 6][0][lane];
     const uint32_t gid = blockIdx.x * MQ_BLOCK + threadIdx.x;
     unsigned long long* spill = F.stack_spill + (size_t)gid * MQ_SPILL_ENTRIES;
-    const uint32_t* tails = F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP;
-    uint32_t* heads = F.ctrl + MQ_CTRL_HEAD0 + round * MQ_CTRL_GROUP;
+    const uint32_t* tails = F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP;
+    uint32_t* heads = F.qctrl + MQ_CTRL_HEAD0 + round * MQ_CTRL_GROUP;
     Ctr ctr = {};
     const uint32_t wave_id = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
     const uint32_t n_eff = queue_view(tails).n_eff;
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
     extern __shared__ uint2 s_dyn[];
     float* lobes = GUIDED ? (float*)(s_dyn + (size_t)(threadIdx.x >> 6) * F.lds_rows2 * 64) + (threadIdx.x & 63) : nullptr;
     const mq_uniform& U = F.u;
-    const QView qv = queue_view(F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const QView qv = queue_view(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
     const uint32_t n = qv.n_eff;
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
@@ -1623,7 +1623,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel(MqSceneDev sc, MqParams P, MqFrame F, int smp, int round) {
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
-    const QView qv = queue_view(F.ctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const QView qv = queue_view(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
     const uint32_t n = qv.n_eff;
     const uint32_t grid_max_x = F.W / (uint32_t)P.distance_mc_grid_width + 1u;
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);

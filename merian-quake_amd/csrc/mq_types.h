@@ -188,6 +188,7 @@ struct MqFrame {
     uint32_t W, H;
     uint32_t tiles_x, tiles_y;
     uint32_t n_local_tiles; // tiles this rank renders
+    uint32_t slot_begin, slot_end; // the pixel slots (64 per local tile) of the sub-pipeline this launch belongs to; [0, n_local_tiles * 64) = the whole rank
     uint32_t rank, world;
     // outputs
     float* irradiance;     // W*H*4 (full image, linear index) -- written for local tiles only
@@ -213,14 +214,18 @@ struct MqFrame {
     uint32_t* upd_head;    // per mc slot, index+1 of the newest queue entry
     MqUpdate* queue;
     uint32_t queue_cap;
-    // control words: see MQ_CTRL_* (sharded tails of the update queue and of every round's ray queue, fetch heads)
+    // control words: see MQ_CTRL_* (sharded tails of the update queue and of every round's ray queue, fetch heads).
+    // ctrl: the rank's block (overflow flags, update-queue tails); qctrl: the block of this launch's sub-pipeline (its
+    // ray-queue tails and fetch heads per round)
     uint32_t* ctrl;
+    uint32_t* qctrl;
     // wavefront state: 160-byte path records per pixel slot, rays / hits per queue position,
     // ping-pong queues of pixel slots
     uint4* paths;          // field-major: field k of pixel slot s at paths[k * n_slots + s]
     uint32_t n_slots;      // pixel slots of this rank (tiles * 64)
     float4* rays;
     uint4* ray_hits;
+    uint4* prim_hits;      // closest hits of the camera rays, per pixel slot (mq_primary_trace_kernel -> mq_primary_kernel); one buffer per frame parity
     uint32_t* queue_slots[2];
     uint32_t ray_cap;      // positions available in rays / ray_hits / queue_slots (2x the pixel slots: shard imbalance margin)
     MqCountersDev* counters;
