@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MQ_ABI_VERSION 1
+#define MQ_ABI_VERSION 2
 
 enum {
     MQ_OK = 0,
@@ -95,6 +95,12 @@ enum {
     MQ_OUT_VOLUME_MV = 9,     /* "volume_mv" RG16F, render_mcpg.cpp:48-50 */
     MQ_OUT_VOLUME_TILES = 10, /* this rank's "volume" tiles, tile-major (second multi-GPU exchange buffer, configs with volume spp > 0) */
     MQ_OUT_DEBUG = 11,        /* "debug" RGBA16F (render_mcpg.cpp:51-52, mcpg.comp:212-277); written when the property "debug output connected" is set */
+    /* the post chain, mq_post_process: res/default_config.json nodes "accum", "volume accum", "add" */
+    MQ_OUT_ACCUM = 12,                /* accum "out" RGBA32F: temporally accumulated irradiance (a = accumulated 2nd moment) */
+    MQ_OUT_ACCUM_HISTORY = 13,        /* accum "history" R32F: frames accumulated per pixel */
+    MQ_OUT_VOLUME_ACCUM = 14,         /* volume accum "out" RGBA32F */
+    MQ_OUT_VOLUME_ACCUM_HISTORY = 15, /* volume accum "history" R32F */
+    MQ_OUT_FINAL = 16,                /* add "out" RGBA32F: accum * albedo + volume accum + first-hit emission */
     MQ_OUT_COUNT
 };
 
@@ -229,6 +235,18 @@ int mq_debug_learn_log_read(mq_ctx* ctx, void* dst_host, size_t cap_records, siz
 int mq_debug_apply_updates(mq_ctx* ctx, const void* records, uint32_t n, const mq_uniform* u);
 #define MQ_PROF_SECTION_COUNT 40
 int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
+
+/* ---- the post chain: temporal accumulation + albedo re-modulation + composition ----
+ * Stands in for the reference graph's "accum" / "volume accum" (merian Accumulate) nodes, the albedo re-modulation of
+ * its denoiser nodes and the "add" node (res/default_config.json:21-133,404-435,473-497); the arithmetic is defined
+ * in merian-quake_amd/csrc/mq_post.hip (merian's node sources are not part of the reference tree).
+ * Call after mq_process of the same frame, on the same stream.  Properties: "accum: alpha", "accum: max history",
+ * "accum: normal threshold", "accum: depth threshold", "accum: enable motion vectors", "accum: reuse border" and the
+ * same six with the prefix "volume accum: " (mq_load_properties_json(ctx, json, "accum") reads them from a graph file).
+ * Needs the whole image on this context (mq_set_partition(0, 1)). */
+int mq_post_process(mq_ctx* ctx, void* stream);
+/* the nodes' "clear event": the next mq_post_process starts a new history */
+int mq_post_clear(mq_ctx* ctx);
 
 /* ---- multi-GPU framebuffer sharding (no reference counterpart) ----
  * Rank r of `world` renders the 8x8-pixel tiles t with t % world == r into MQ_OUT_TILES

@@ -23,7 +23,8 @@
 
 // launchers implemented in mq_kernels.hip
 int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s);
-int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool packet, int grid, hipStream_t s);
+int mq_packet_stack_entries();
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s);
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s);
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, uint32_t sequential_mc_total, hipStream_t s);
@@ -39,6 +40,9 @@ int mq_launch_forward_project(const MqParams& P, const MqFrame& F, int grid, hip
 int mq_launch_volume_sample(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s);
 int mq_launch_volume_shade(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s);
 int mq_launch_volume_finish(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+// mq_post.hip
+int mq_launch_accumulate(const float* accum_params6, uint32_t W, uint32_t H, const void* src, const void* mv, const void* gb, const void* prev_gb, const void* prev_out, const void* prev_hist, void* out, void* hist, int first, hipStream_t s);
+int mq_launch_compose(uint32_t W, uint32_t H, const void* accum, const void* albedo, const void* vol, const void* emission, void* final_out, hipStream_t s);
 int mq_render_block_size();
 int mq_spill_entries();
 
@@ -63,6 +67,7 @@ struct mq_ctx {
     // per-frame slots on every commit (quake_node.cpp:847-983); layout in mq_scene_commit.
     std::vector<MqNode> s_nodes; std::vector<MqTri> s_tris; // the static tree as built
     float s_sah = 0.0f;
+    uint32_t s_depth = 0, d_depth = 0; // levels of 8-wide nodes in the static / per-frame tree (the packet kernel's shared stack must hold them)
     bool static_dirty = true, tex_dirty = true;
     bool joined = false;               // both trees present
     uint32_t n_static_nodes = 0, n_static_tris = 0; // the static part of nodes / tris
@@ -83,6 +88,8 @@ struct mq_ctx {
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
     DevBuf d_prev_vdepth, d_dist_mc;
+    DevBuf d_post_prev_gb, d_post_prev_out[2], d_post_prev_hist[2]; // post chain: last frame's g-buffer, accumulated images and histories (surface, volume)
+    bool post_first = true;
     DevBuf d_learn_log, d_learn_count; // "debug: log learning writes": allocated by the first frame that logs
     uint32_t learn_log_cap = 0;
     uint32_t dist_mc_n = 0;
@@ -220,6 +227,19 @@ const PropDesc k_props[] = {
     {"enable albedo mipmap", PT_BOOL, POFF(enable_albedo_mipmap), false, {}},
     {"enable emission mipmap", PT_BOOL, POFF(enable_emission_mipmap), false, {}},
     {"debug output connected", PT_BOOL, POFF(debug_output_connected), false, {}},
+    // post chain: the Accumulate nodes "accum" / "volume accum" of the graph (res/default_config.json:404-428,473-497)
+    {"accum: alpha", PT_FLOAT, POFF(accum_alpha), false, {}},
+    {"accum: max history", PT_FLOAT, POFF(accum_max_history), false, {}},
+    {"accum: normal threshold", PT_FLOAT, POFF(accum_normal_threshold), false, {}},
+    {"accum: depth threshold", PT_FLOAT, POFF(accum_depth_threshold), false, {}},
+    {"accum: enable motion vectors", PT_BOOL, POFF(accum_enable_mv), false, {}},
+    {"accum: reuse border", PT_BOOL, POFF(accum_reuse_border), false, {}},
+    {"volume accum: alpha", PT_FLOAT, POFF(vaccum_alpha), false, {}},
+    {"volume accum: max history", PT_FLOAT, POFF(vaccum_max_history), false, {}},
+    {"volume accum: normal threshold", PT_FLOAT, POFF(vaccum_normal_threshold), false, {}},
+    {"volume accum: depth threshold", PT_FLOAT, POFF(vaccum_depth_threshold), false, {}},
+    {"volume accum: enable motion vectors", PT_BOOL, POFF(vaccum_enable_mv), false, {}},
+    {"volume accum: reuse border", PT_BOOL, POFF(vaccum_reuse_border), false, {}},
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
@@ -345,6 +365,7 @@ void free_frame_state(mq_ctx* c) {
     for (auto& b : c->d_out) dev_free(b);
     dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
+    dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
     dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0;
     dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); c->shaded_valid[0] = c->shaded_valid[1] = false;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
@@ -364,7 +385,7 @@ size_t queue_entries_needed(const mq_ctx* c) {
     return segs + segs / 8 + (size_t)MQ_SHARDS * 64 * 4;
 }
 
-const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8};
+const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8, 16, 4, 16, 4, 16};
 
 void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     memset(d, 0, sizeof *d);
@@ -512,7 +533,9 @@ int mq_load_properties_json(mq_ctx* c, const char* json_text, const char* node_n
             std::string sval;
             if (is_str) sval = jp.str(); else { jp.skip(); sval.assign(jp.s + v0, jp.i - v0); }
             if (!jp.ok) return fail(c, MQ_EIO, "malformed property value");
-            if (find_prop(k.c_str())) { int r = mq_set_property_str(c, k.c_str(), sval.c_str()); if (r < 0) return r; reconnect |= r; applied++; }
+            const std::string prefixed = std::string(node_name) + ": " + k; // the post chain's nodes: "accum: alpha", "volume accum: alpha", ...
+            const std::string& key = find_prop(prefixed.c_str()) ? prefixed : k;
+            if (find_prop(key.c_str())) { int r = mq_set_property_str(c, key.c_str(), sval.c_str()); if (r < 0) return r; reconnect |= r; applied++; }
             if (jp.eat(',')) continue;
             break;
         }
@@ -636,12 +659,12 @@ int mq_scene_commit(mq_ctx* c) {
     const bool static_rebuilt = c->static_dirty;
     if (c->static_dirty) {
         flatten_slots(c, true, flat);
-        if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, &c->s_sah, err)) return fail(c, MQ_EINVAL, "bvh build: " + err);
+        if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, &c->s_sah, err, &c->s_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
         c->static_dirty = false;
     }
     std::vector<MqNode> d_nodes; std::vector<MqTri> d_tris; float d_sah = 0.0f;
     flatten_slots(c, false, flat);
-    if (!mq_build_cwbvh(flat, d_nodes, d_tris, &d_sah, err)) return fail(c, MQ_EINVAL, "bvh build: " + err);
+    if (!mq_build_cwbvh(flat, d_nodes, d_tris, &d_sah, err, &c->d_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
     const size_t ns = c->s_nodes.size(), nd = d_nodes.size(), ts = c->s_tris.size(), td = d_tris.size();
     // layout: the static tree as built, then the per-frame tree (indices offset); the traversal starts at node 0 and
     // visits the per-frame root (MqSceneDev::dyn_root) last.  Without static geometry the per-frame tree is the tree.
@@ -830,6 +853,9 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_qslots[1], (size_t)c->ray_cap * 4))) return r;
     if ((r = dev_alloc(c, c->d_prev_vdepth, (size_t)w * h * 2))) return r;
     HIPCHK(c, hipMemset(c->d_prev_vdepth.p, 0, c->d_prev_vdepth.bytes));
+    if ((r = dev_alloc(c, c->d_post_prev_gb, (size_t)w * h * 16))) return r;
+    for (int k = 0; k < 2; k++) { if ((r = dev_alloc(c, c->d_post_prev_out[k], (size_t)w * h * 16))) return r; if ((r = dev_alloc(c, c->d_post_prev_hist[k], (size_t)w * h * 4))) return r; }
+    c->post_first = true;
     c->dist_mc_n = (uint32_t)(d.state_bytes_volume_distancemc / sizeof(MqDistMC));
     if ((r = dev_alloc(c, c->d_dist_mc, d.state_bytes_volume_distancemc))) return r;
     c->iteration = 0; c->connected = true; c->params_dirty = true; c->volume_outputs_zero = true; // outputs were cleared above
@@ -1023,9 +1049,11 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         for (int k = 1; k < S; k++) { HIPCHK(c, hipEventRecord(c->ev_join[k - 1], st(k))); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0)); }
         return MQ_OK;
     };
+    // a shared-stack entry per level with pending siblings, +1 for the per-frame root waiting at the bottom
+    const bool packet = (int)std::max(c->s_depth, c->d_depth) + 2 <= mq_packet_stack_entries() && !getenv("MQ_DEBUG_NO_PACKET");
     if (!c->count_enabled) // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
         for (int k = 0; k < S; k++) {
-            e = mq_launch_primary_trace(c->scene, c->params, FS[k], overlap_pt ? c->grid_frame[1] : sub_grid(1), overlap_pt ? c->pt_stream : st(k));
+            e = mq_launch_primary_trace(c->scene, c->params, FS[k], packet, overlap_pt ? c->grid_frame[1] : sub_grid(1), overlap_pt ? c->pt_stream : st(k));
             if (e) return fail(c, MQ_EHIP, std::string("primary trace launch: ") + hipGetErrorString((hipError_t)e));
         }
     if (overlap_pt) {
@@ -1227,6 +1255,41 @@ int mq_debug_state_write(mq_ctx* c, int which, const void* src, size_t bytes) {
     if (c->iteration == 0) return fail(c, MQ_ESTATE, "process one frame before writing state (the first frame zeroes it)");
     HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(b->p, src, bytes, hipMemcpyHostToDevice));
+    return MQ_OK;
+}
+
+// ---- post chain (mq_post.hip): accum + volume accum + add ------------------------------------------------------
+int mq_post_clear(mq_ctx* c) { if (!c) return MQ_EINVAL; c->post_first = true; return MQ_OK; }
+int mq_post_process(mq_ctx* c, void* stream) {
+    if (!c) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    if (!c->connected) return fail(c, MQ_ESTATE, "mq_post_process before mq_connect");
+    if (c->world != 1) return fail(c, MQ_ESTATE, "the post chain needs the whole image on this context (partition 0 of 1)");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    const MqProps& q = c->props;
+    const float A[2][6] = {{q.accum_alpha, q.accum_max_history, (float)std::cos((double)q.accum_normal_threshold), q.accum_depth_threshold, q.accum_enable_mv ? 1.0f : 0.0f, q.accum_reuse_border ? 1.0f : 0.0f},
+                           {q.vaccum_alpha, q.vaccum_max_history, (float)std::cos((double)q.vaccum_normal_threshold), q.vaccum_depth_threshold, q.vaccum_enable_mv ? 1.0f : 0.0f, q.vaccum_reuse_border ? 1.0f : 0.0f}};
+    const int src[2] = {MQ_OUT_IRRADIANCE, MQ_OUT_VOLUME}, mv[2] = {MQ_OUT_GB_MV, MQ_OUT_VOLUME_MV}, out[2] = {MQ_OUT_ACCUM, MQ_OUT_VOLUME_ACCUM}, hist[2] = {MQ_OUT_ACCUM_HISTORY, MQ_OUT_VOLUME_ACCUM_HISTORY};
+    const size_t px = (size_t)c->W * c->H;
+    for (int k = 0; k < 2; k++) {
+        // volume accum.mv <- render_markovchain.volume_mv: only written by frames with a volume pass; without one there is no motion to follow
+        const bool have_vmv = k == 0 || (c->params.volume_spp > 0 && !c->volume_outputs_zero);
+        float Ak[6]; memcpy(Ak, A[k], sizeof Ak); if (!have_vmv) Ak[4] = 0.0f;
+        int e = mq_launch_accumulate(Ak, c->W, c->H, c->d_out[src[k]].p, c->d_out[mv[k]].p, c->d_out[MQ_OUT_GBUFFER].p, c->d_post_prev_gb.p, c->d_post_prev_out[k].p, c->d_post_prev_hist[k].p,
+                                     c->d_out[out[k]].p, c->d_out[hist[k]].p, c->post_first ? 1 : 0, s);
+        if (e) return fail(c, MQ_EHIP, std::string("accumulate launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    int e = mq_launch_compose(c->W, c->H, c->d_out[MQ_OUT_ACCUM].p, c->d_out[MQ_OUT_GB_ALBEDO].p, c->d_out[MQ_OUT_VOLUME_ACCUM].p, c->d_out[MQ_OUT_GB_IRRADIANCE].p, c->d_out[MQ_OUT_FINAL].p, s);
+    if (e) return fail(c, MQ_EHIP, std::string("compose launch: ") + hipGetErrorString((hipError_t)e));
+    // the graph's delay-1 connections (prev_out, prev_history, prev_gbuffer)
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(c, hipMemcpyAsync(c->d_post_prev_out[k].p, c->d_out[out[k]].p, px * 16, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_post_prev_hist[k].p, c->d_out[hist[k]].p, px * 4, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_post_prev_gb.p, c->d_out[MQ_OUT_GBUFFER].p, px * 16, hipMemcpyDeviceToDevice, s));
+    c->post_first = false;
+    c->last_stream = s;
     return MQ_OK;
 }
 

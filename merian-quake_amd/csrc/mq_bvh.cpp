@@ -117,7 +117,8 @@ inline float exp2i(int e) { uint32_t b = (uint32_t)(e + 127) << 23; float f; mem
 
 // Build into `out_nodes` / `out_tris` (triangles re-ordered into leaf order). `pad` widens every
 // box so the float slab test stays conservative next to the exact triangle test.
-bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err) {
+bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err, uint32_t* depth_out) {
+    if (depth_out) *depth_out = 0;
     out_nodes.clear(); out_tris.clear();
     if (sah_cost) *sah_cost = 0.0f;
     const uint32_t n = (uint32_t)tris.size();
@@ -143,15 +144,17 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
     auto T1 = std::chrono::steady_clock::now();
 
     // ---- collapse to 8-wide ---------------------------------------------------------------------
-    struct Work { int bnode; uint32_t out_index; };
+    struct Work { int bnode; uint32_t out_index; uint32_t depth; };
+    uint32_t max_depth = 0;
     std::queue<Work> q;
     out_nodes.emplace_back();
-    q.push({root, 0});
+    q.push({root, 0, 1});
     out_tris.reserve(n);
     double sah = 0.0;
     const float root_area = std::max(B.nodes[root].box.area(), 1e-30f);
     while (!q.empty()) {
         Work w = q.front(); q.pop();
+        max_depth = std::max(max_depth, w.depth);
         // gather up to 8 children: repeatedly open the internal child with the largest area
         int ch[8]; int nc = 0;
         const BNode& bn = B.nodes[w.bnode];
@@ -229,7 +232,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
             if (cn.count == 0) {
                 node.imask |= (uint8_t)(1u << s);
                 node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
-                q.push({c, next_child++});
+                q.push({c, next_child++, w.depth + 1});
                 sah += (double)cn.box.area() / root_area;
             } else {
                 uint32_t unary = cn.count == 1 ? 1u : (cn.count == 2 ? 3u : 7u);
@@ -243,6 +246,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
     }
     if (getenv("MQ_DEBUG_BUILD_TIMES")) fprintf(stderr, "bvh build: %u tris, binary tree %.1f ms, collapse %.1f ms\n", n, std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T1).count());
     if (sah_cost) *sah_cost = (float)sah;
+    if (depth_out) *depth_out = max_depth; // levels of 8-wide nodes
     if (out_tris.size() != n) { err = "internal: triangle count mismatch after collapse"; return false; }
     return true;
 }

@@ -1,5 +1,6 @@
 // mq_host.h -- host-side internals of libmqhip (scene container, property table, launch glue).
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -76,12 +77,17 @@ struct MqProps {
     bool overlap_camera_rays = false; // scheduling of this build: the camera rays of frame n + 1 traced beside the kernels of frame n (measured: no gain)
     int pipelines = 1; // scheduling of this build, not a reference property: sub-pipelines per frame (mq_api.cpp mq_process)
     bool sequential_update_pass = false; // test hook: the update pass in the reference's dispatch order, one slot after the other
+    // post chain: the "accum" and "volume accum" nodes of res/default_config.json (header defaults = its values)
+    float accum_alpha = 0.951f, accum_max_history = INFINITY, accum_normal_threshold = 0.645771861076355f, accum_depth_threshold = 0.026403000578284264f;
+    bool accum_enable_mv = true, accum_reuse_border = true;
+    float vaccum_alpha = 0.902f, vaccum_max_history = INFINITY, vaccum_normal_threshold = 3.1415927410125732f, vaccum_depth_threshold = 0.28402701020240784f;
+    bool vaccum_enable_mv = true, vaccum_reuse_border = true;
     // named quirk switches: on = what the reference's shaders compute, off = the evident intent
     bool quirk_lc_max_wo_p = true; // mcpg.comp:170 `max(wo_p, 10)`
     bool quirk_n16_wrap = true;    // mc.glsl:26 `N * N` on a uint16_t (grid.h:19): wraps, 0 at N = 256 / 512 / 768 / 1024
 };
 
-bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err);
+bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err, uint32_t* depth_out = nullptr);
 
 struct mq_ctx;
 bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string& err);

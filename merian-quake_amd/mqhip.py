@@ -19,7 +19,7 @@ MQ_MAX_GEOMETRIES = 16
 MQ_GEO_OPAQUE, MQ_GEO_STATIC = 1, 2
 MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
 (OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_VOLUME, OUT_VOLUME_DEPTH,
- OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_DEBUG, OUT_COUNT) = range(13)
+ OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_DEBUG, OUT_ACCUM, OUT_ACCUM_HISTORY, OUT_VOLUME_ACCUM, OUT_VOLUME_ACCUM_HISTORY, OUT_FINAL, OUT_COUNT) = range(18)
 MQ_ENODEVICE = -2
 
 EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),
@@ -124,6 +124,8 @@ def load_library(path=None):
         "mq_debug_state_read": (i32, [P, i32, vp, sz]),
         "mq_debug_state_write": (i32, [P, i32, vp, sz]),
         "mq_debug_section_clocks": (i32, [P, C.POINTER(C.c_uint64), i32, i32]),
+        "mq_post_process": (i32, [P, vp]),
+        "mq_post_clear": (i32, [P]),
         "mq_debug_learn_log_read": (i32, [P, vp, sz, C.POINTER(sz)]),
         "mq_debug_apply_updates": (i32, [P, vp, u32, C.POINTER(Uniform)]),
         "mq_set_partition": (i32, [P, i32, i32]),
@@ -371,6 +373,16 @@ class Context:
     def state_write(self, which, a):
         a = np.ascontiguousarray(a, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE)[which])
         self._chk(self.lib.mq_debug_state_write(self.h, which, a.ctypes.data, a.nbytes))
+
+    def post_process(self, stream=None):
+        self._chk(self.lib.mq_post_process(self.h, stream))
+
+    def post_clear(self):
+        self._chk(self.lib.mq_post_clear(self.h))
+
+    def image(self, which):
+        """an RGBA32F output as (H, W, 4) float32"""
+        return self.read_output(which).view(np.float32).reshape(self.H, self.W, 4)
 
     def learn_log(self):
         """Records of the last frame's learning-write log (property "debug: log learning writes"): (n, 16) uint32."""

@@ -106,6 +106,10 @@ struct orc_ctx {
     /* learning-write log (params.log_learning) and the touch list of orc_debug_apply_updates */
     uint32_t* llog; size_t llog_cap, llog_n;
     uint32_t* touch; size_t touch_cap, touch_n;
+    /* post chain */
+    float post_par[2][6];
+    float* post_out[2]; float* post_hist[2]; float* post_prev_out[2]; float* post_prev_hist[2]; gbuf_t* post_prev_gb; float* post_final;
+    int post_first; int volume_ran;
 };
 
 /* ---------------------------------------------------------------- params */
@@ -142,6 +146,10 @@ void orc_params_json_defaults(orc_params_t* p) { /* default_config.json:599-638 
 orc_ctx* orc_create(const orc_params_t* p) {
     orc_ctx* c = (orc_ctx*)calloc(1, sizeof *c);
     if (!c) return NULL;
+    { /* the "accum" / "volume accum" nodes of res/default_config.json:404-428,473-497 */
+        const float a[6] = {0.951f, INFINITY, 0.645771861076355f, 0.026403000578284264f, 1.0f, 1.0f}, v[6] = {0.902f, INFINITY, 3.1415927410125732f, 0.28402701020240784f, 1.0f, 1.0f};
+        memcpy(c->post_par[0], a, sizeof a); memcpy(c->post_par[1], v, sizeof v);
+    }
     if (p) c->p = *p; else orc_params_header_defaults(&c->p);
     c->tex = (tex_t*)calloc(MAX_GLTEXTURES, sizeof(tex_t));
     for (int i = 0; i < 256; i++) { /* sRGB EOTF, evaluated in double then rounded once */
@@ -152,6 +160,8 @@ orc_ctx* orc_create(const orc_params_t* p) {
     return c;
 }
 static void free_state(orc_ctx* c) {
+    for (int k = 0; k < 2; k++) { free(c->post_out[k]); free(c->post_hist[k]); free(c->post_prev_out[k]); free(c->post_prev_hist[k]); c->post_out[k] = c->post_hist[k] = c->post_prev_out[k] = c->post_prev_hist[k] = NULL; }
+    free(c->post_prev_gb); free(c->post_final); c->post_prev_gb = NULL; c->post_final = NULL;
     free(c->llog); c->llog = NULL; c->llog_cap = c->llog_n = 0;
     free(c->mc); free(c->lc); free(c->upd_count); free(c->upd_rec); free(c->upd_pool); free(c->upd_touched);
     free(c->irradiance); free(c->gb_albedo); free(c->gb_irr); free(c->gb_mv); free(c->gbuffer); free(c->hits);
@@ -512,6 +522,8 @@ int orc_connect(orc_ctx* c, uint32_t w, uint32_t h) {
     c->volume = (float*)calloc(px, 16); c->volume_depth = (uint16_t*)calloc(px, 2); c->prev_volume_depth = (uint16_t*)calloc(px, 2); c->volume_mv = (uint16_t*)calloc(px, 4); c->debug = (uint16_t*)calloc(px, 8);
     { uint32_t gw = c->p.distance_mc_grid_width > 0 ? (uint32_t)c->p.distance_mc_grid_width : 25u; /* render_mcpg.cpp:80-82 */
       c->dist_mc_n = (w / gw + 2) * (h / gw + 2) * 10u; c->dist_mc = (distmc_t*)calloc(c->dist_mc_n, sizeof(distmc_t)); }
+    for (int k = 0; k < 2; k++) { c->post_out[k] = (float*)calloc(px, 16); c->post_hist[k] = (float*)calloc(px, 4); c->post_prev_out[k] = (float*)calloc(px, 16); c->post_prev_hist[k] = (float*)calloc(px, 4); }
+    c->post_prev_gb = (gbuf_t*)calloc(px, sizeof(gbuf_t)); c->post_final = (float*)calloc(px, 16); c->post_first = 1; c->volume_ran = 0;
     c->iteration = 0;
     if (!c->mc || !c->lc || !c->upd_count || !c->upd_rec || !c->upd_pool || !c->irradiance || !c->hits) return -1;
     return 0;
@@ -1414,9 +1426,69 @@ int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
         if (c->p.volume_forward_project && c->iteration != 0)
             for (uint32_t y = 0; y < c->H; y++) for (uint32_t x = 0; x < c->W; x++) forward_project_pixel(c, x, y);
         run_pass(c, 2, threads);
+        c->volume_ran = u->cam_x[3] > 0.0f;
         /* keep the touched-slot list of the volume pass for the next frame's update pass */
-    } else memset(c->volume, 0, px * 16);
+    } else { memset(c->volume, 0, px * 16); c->volume_ran = 0; }
     c->iteration++;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- post chain (definitions: DESIGN.md section 3) */
+
+int orc_post_set_params(orc_ctx* c, int which, const float* six) { if (which < 0 || which > 1) return -1; memcpy(c->post_par[which], six, 24); return 0; }
+void orc_post_clear(orc_ctx* c) { c->post_first = 1; }
+const void* orc_post_output(orc_ctx* c, int which, size_t* bytes) {
+    size_t px = (size_t)c->W * c->H;
+    switch (which) {
+    case 0: case 2: if (bytes) *bytes = px * 16; return c->post_out[which / 2];
+    case 1: case 3: if (bytes) *bytes = px * 4; return c->post_hist[which / 2];
+    case 4: if (bytes) *bytes = px * 16; return c->post_final;
+    }
+    return NULL;
+}
+static void accumulate(orc_ctx* c, int k, const float* src, const uint16_t* mv) {
+    const float alpha = c->post_par[k][0], max_history = c->post_par[k][1], cos_thr = (float)cos((double)c->post_par[k][2]), depth_thr = c->post_par[k][3];
+    const int enable_mv = c->post_par[k][4] != 0.0f && mv != NULL, reuse_border = c->post_par[k][5] != 0.0f;
+    const uint32_t W = c->W, H = c->H;
+    for (uint32_t iy = 0; iy < H; iy++) for (uint32_t ix = 0; ix < W; ix++) {
+        const size_t i = (size_t)iy * W + ix;
+        const float* s = src + 4 * i;
+        float h = 1.0f, o[4] = {s[0], s[1], s[2], s[3]};
+        if (!c->post_first) {
+            float mx = 0.0f, my = 0.0f;
+            if (enable_mv) { mx = orc_h2f(mv[2 * i]); my = orc_h2f(mv[2 * i + 1]); }
+            float qx = floorf(((float)ix + mx) + 0.5f), qy = floorf(((float)iy + my) + 0.5f);
+            int valid = qx >= 0.0f && qy >= 0.0f && qx < (float)W && qy < (float)H;
+            if (!valid && reuse_border && qx == qx && qy == qy) { qx = oclamp(qx, 0.0f, (float)W - 1.0f); qy = oclamp(qy, 0.0f, (float)H - 1.0f); valid = 1; }
+            if (valid) {
+                const size_t q = (size_t)(uint32_t)qy * W + (uint32_t)qx;
+                const gbuf_t* g = &c->gbuffer[i]; const gbuf_t* pg = &c->post_prev_gb[q];
+                const float ze = g->linear_z + g->vel_z, zp = pg->linear_z;
+                valid = vdot(orc_decode_normal(g->enc_normal), orc_decode_normal(pg->enc_normal)) >= cos_thr && fabsf(ze - zp) <= depth_thr * omax(ze, zp);
+                if (valid) {
+                    h = omin(c->post_prev_hist[k][q] + 1.0f, max_history);
+                    const float a = omax(1.0f / h, 1.0f - alpha);
+                    const float* p = c->post_prev_out[k] + 4 * q;
+                    for (int ch = 0; ch < 4; ch++) o[ch] = omix(p[ch], s[ch], a);
+                }
+            }
+        }
+        memcpy(c->post_out[k] + 4 * i, o, 16); c->post_hist[k][i] = h;
+    }
+}
+int orc_post_process(orc_ctx* c) {
+    if (!c->post_final) return -1;
+    const size_t px = (size_t)c->W * c->H;
+    accumulate(c, 0, c->irradiance, c->gb_mv);
+    accumulate(c, 1, c->volume, c->volume_ran ? c->volume_mv : NULL); /* volume_mv exists only after a volume pass */
+    for (size_t i = 0; i < px; i++) { /* add: accum * albedo (the denoiser node's re-modulation) + volume accum + first-hit emission */
+        const float* a = c->post_out[0] + 4 * i; const float* v = c->post_out[1] + 4 * i; float* f = c->post_final + 4 * i;
+        for (int ch = 0; ch < 3; ch++) f[ch] = (a[ch] * orc_h2f(c->gb_albedo[4 * i + ch]) + v[ch]) + orc_h2f(c->gb_irr[4 * i + ch]);
+        f[3] = 1.0f;
+    }
+    for (int k = 0; k < 2; k++) { memcpy(c->post_prev_out[k], c->post_out[k], px * 16); memcpy(c->post_prev_hist[k], c->post_hist[k], px * 4); }
+    memcpy(c->post_prev_gb, c->gbuffer, px * sizeof(gbuf_t));
+    c->post_first = 0;
     return 0;
 }
 

@@ -170,6 +170,17 @@ int orc_learn_log_reset(orc_ctx* c, size_t capacity);
  * writes -- lets a test find slots whose applications interfere; *n_touches = pairs produced. */
 int orc_debug_apply_updates(orc_ctx* c, const uint32_t* records, size_t n, const orc_uniform_t* u, uint32_t* touches, size_t touch_cap, size_t* n_touches);
 
+/* ---- post chain: the graph's "accum" / "volume accum" nodes, albedo re-modulation and the "add" node
+ * (res/default_config.json:21-133,404-435,473-497).  merian's node sources are absent from the reference tree: the
+ * arithmetic is DEFINED in DESIGN.md section 3 ("post chain") and restated here and in mq_post.hip independently.
+ * params: which 0 = accum, 1 = volume accum; six floats: alpha, max history, normal threshold (radians), depth
+ * threshold, enable motion vectors, reuse border.  Outputs: 0 accum RGBA32F, 1 accum history R32F, 2 volume accum
+ * RGBA32F, 3 volume accum history R32F, 4 final RGBA32F. */
+int orc_post_set_params(orc_ctx* c, int which, const float* six);
+int orc_post_process(orc_ctx* c); /* after orc_process of the same frame */
+void orc_post_clear(orc_ctx* c);
+const void* orc_post_output(orc_ctx* c, int which, size_t* bytes);
+
 /* closest-hit queries (raytrace.glsl:82-119 semantics: back-face cull, alpha any-hit, tmin 0,
  * tmax 1e4).  out_prim = (slot << 28 | prim) or 0xffffffff on miss. */
 int orc_trace_rays(orc_ctx* c, const float* org, const float* dir, uint32_t n, uint32_t* out_prim,

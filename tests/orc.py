@@ -69,6 +69,11 @@ def lib():
         l.orc_learn_log.argtypes = [P, C.POINTER(C.c_size_t)]
         l.orc_learn_log_reset.argtypes = [P, C.c_size_t]
         l.orc_debug_apply_updates.argtypes = [P, P, C.c_size_t, P, P, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.orc_post_set_params.argtypes = [P, C.c_int, P]
+        l.orc_post_process.argtypes = [P]
+        l.orc_post_clear.argtypes = [P]
+        l.orc_post_output.restype = C.c_void_p
+        l.orc_post_output.argtypes = [P, C.c_int, C.POINTER(C.c_size_t)]
         l.orc_params_header_defaults.argtypes = [C.POINTER(Params)]
         l.orc_params_json_defaults.argtypes = [C.POINTER(Params)]
         _lib = l
@@ -172,6 +177,26 @@ class Oracle:
         dt = (self.MC_DTYPE, self.LC_DTYPE, np.dtype([("sum_w", "<f4"), ("N", "<u4"), ("m0", "<f4"), ("m1", "<f4")]))[which]
         assert p and eb.value == dt.itemsize, (eb.value, dt.itemsize)
         return np.frombuffer((C.c_char * (n.value * eb.value)).from_address(p), dtype=dt)
+
+    (POST_ACCUM, POST_ACCUM_HISTORY, POST_VOLUME_ACCUM, POST_VOLUME_ACCUM_HISTORY, POST_FINAL) = range(5)
+
+    def post_params_from_ctx(self, ctx):
+        """the post chain's properties of a product context ("accum: ..." / "volume accum: ...")"""
+        for k, prefix in enumerate(("accum: ", "volume accum: ")):
+            six = np.array([ctx.get_property(prefix + n) for n in ("alpha", "max history", "normal threshold", "depth threshold", "enable motion vectors", "reuse border")], np.float32)
+            assert self.l.orc_post_set_params(self.h, k, _ptr(six)) == 0
+
+    def post_process(self):
+        assert self.l.orc_post_process(self.h) == 0
+
+    def post_clear(self):
+        self.l.orc_post_clear(self.h)
+
+    def post_output(self, which):
+        n = C.c_size_t()
+        p = self.l.orc_post_output(self.h, which, C.byref(n))
+        a = np.frombuffer((C.c_char * n.value).from_address(p), dtype=np.float32).copy()
+        return a.reshape(self.H, self.W, 4) if which in (0, 2, 4) else a.reshape(self.H, self.W)
 
     def learn_log_reset(self, capacity):
         assert self.l.orc_learn_log_reset(self.h, capacity) == 0

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(mq, mqlib):
     for name in declared:
         assert hasattr(mqlib, name), "libmqhip.so does not export %s" % name
     assert declared == set(mqlib._mq_symbols), declared ^ set(mqlib._mq_symbols)
-    assert mqlib.mq_abi_version() == 1
+    assert mqlib.mq_abi_version() == 2
     assert ctypes.sizeof(mq.Uniform) == 124  # res/shader/scene_info.glsl.h:18-32
     assert mq.EXT_DTYPE.itemsize == 28       # src/game/quake_helpers.hpp:10-34
 
