@@ -101,6 +101,10 @@ enum {
     MQ_OUT_VOLUME_ACCUM = 14,         /* volume accum "out" RGBA32F */
     MQ_OUT_VOLUME_ACCUM_HISTORY = 15, /* volume accum "history" R32F */
     MQ_OUT_FINAL = 16,                /* add "out" RGBA32F: accum * albedo + volume accum + first-hit emission */
+    /* the ReSTIR DI node, mq_restir_process: src/render_restir/renderer_restir.cpp:75-96 */
+    MQ_OUT_RESTIR_IRRADIANCE = 17,    /* "irradiance" RGBA32F (direct light at the first hit, albedo excluded; a = 1) */
+    MQ_OUT_RESTIR_MOMENTS = 18,       /* "moments" RG32F: luminance, luminance^2 */
+    MQ_OUT_RESTIR_RESERVOIRS = 19,    /* "reservoirs": 64 B/pixel ReSTIRDIReservoir, res/shader/render_restir/restir_di_reservoir.glsl.h:8-27 */
     MQ_OUT_COUNT
 };
 
@@ -247,6 +251,18 @@ int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
 int mq_post_process(mq_ctx* ctx, void* stream);
 /* the nodes' "clear event": the next mq_post_process starts a new history */
 int mq_post_clear(mq_ctx* ctx);
+
+/* ---- the ReSTIR DI render node: "Renderer (ReSTIR)" of src/merian-quake.cpp:191-199 ----
+ * RendererRESTIR::process, src/render_restir/renderer_restir.cpp:129-251: generate samples -> [temporal reuse] ->
+ * [spatial reuse] -> shade (or the clear pass when render == 0), on the g-buffer outputs (hits, gbuffer, mv) that the
+ * mq_process call of the same frame left on this context (run it with "spp" 0 if only the g-buffer node is wanted).
+ * Properties: the reference's keys (renderer_restir.cpp:253-325) with the prefix "restir: " -- "restir: spp",
+ * "restir: seed", "restir: randomize seed", "restir: enable temporal reuse", "restir: temporal normal threshold"
+ * (radians), "restir: temporal depth threshold", "restir: temporal clamp m", "restir: temporal bias correction",
+ * "restir: boiling filter strength", "restir: apply mv", "restir: spatial reuse iterations", "restir: spatial normal
+ * threshold", "restir: spatial depth threshold", "restir: spatital radius" (sic), "restir: spatial bias correction",
+ * "restir: shade visibility".  Needs the whole image on this context (partition 0 of 1). */
+int mq_restir_process(mq_ctx* ctx, const mq_uniform* u, int render, void* stream);
 
 /* ---- multi-GPU framebuffer sharding (no reference counterpart) ----
  * Rank r of `world` renders the 8x8-pixel tiles t with t % world == r into MQ_OUT_TILES

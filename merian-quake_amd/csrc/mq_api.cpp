@@ -40,6 +40,9 @@ int mq_launch_forward_project(const MqParams& P, const MqFrame& F, int grid, hip
 int mq_launch_volume_sample(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s);
 int mq_launch_volume_shade(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s);
 int mq_launch_volume_finish(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
+// mq_restir.h
+int mq_launch_restir(const MqSceneDev& sc, const MqParams& P, const MqRestirParams& R, const MqRestirFrame& F, int pass, int grid, hipStream_t s);
+
 // mq_post.hip
 int mq_launch_accumulate(const float* accum_params6, uint32_t W, uint32_t H, const void* src, const void* mv, const void* gb, const void* prev_gb, const void* prev_out, const void* prev_hist, void* out, void* hist, int first, hipStream_t s);
 int mq_launch_compose(uint32_t W, uint32_t H, const void* accum, const void* albedo, const void* vol, const void* emission, void* final_out, hipStream_t s);
@@ -88,6 +91,8 @@ struct mq_ctx {
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
     DevBuf d_prev_vdepth, d_dist_mc;
+    DevBuf d_restir_pong, d_restir_prev, d_restir_prev_gb; // ReSTIR: ping-pong partner of the "reservoirs" output, last frame's reservoirs and g-buffer (the graph's delay-1 inputs)
+    uint64_t restir_iteration = 0; bool restir_seeded = false; uint32_t restir_seed_in_use = 0;
     DevBuf d_post_prev_gb, d_post_prev_out[2], d_post_prev_hist[2]; // post chain: last frame's g-buffer, accumulated images and histories (surface, volume)
     bool post_first = true;
     DevBuf d_learn_log, d_learn_count; // "debug: log learning writes": allocated by the first frame that logs
@@ -240,12 +245,30 @@ const PropDesc k_props[] = {
     {"volume accum: depth threshold", PT_FLOAT, POFF(vaccum_depth_threshold), false, {}},
     {"volume accum: enable motion vectors", PT_BOOL, POFF(vaccum_enable_mv), false, {}},
     {"volume accum: reuse border", PT_BOOL, POFF(vaccum_reuse_border), false, {}},
+    // ReSTIR DI node: renderer_restir.cpp:253-325
+    {"restir: randomize seed", PT_BOOL, POFF(restir_randomize_seed), false, {}},
+    {"restir: seed", PT_UINT, POFF(restir_seed), false, {}},
+    {"restir: spp", PT_INT, POFF(restir_spp), false, {}},
+    {"restir: enable temporal reuse", PT_BOOL, POFF(restir_temporal_reuse), false, {}},
+    {"restir: temporal normal threshold", PT_FLOAT, POFF(restir_temporal_normal_angle), false, {}},
+    {"restir: temporal depth threshold", PT_FLOAT, POFF(restir_temporal_depth), false, {}},
+    {"restir: temporal clamp m", PT_INT, POFF(restir_temporal_clamp_m), false, {}},
+    {"restir: temporal bias correction", PT_OPTION, POFF(restir_temporal_bias), false, {"none", "basic", "raytraced", "raytraced previous bvh"}},
+    {"restir: boiling filter strength", PT_FLOAT, POFF(restir_boiling), false, {}},
+    {"restir: apply mv", PT_BOOL, POFF(restir_apply_mv), false, {}},
+    {"restir: spatial reuse iterations", PT_INT, POFF(restir_spatial_iterations), false, {}},
+    {"restir: spatial normal threshold", PT_FLOAT, POFF(restir_spatial_normal_angle), false, {}},
+    {"restir: spatial depth threshold", PT_FLOAT, POFF(restir_spatial_depth), false, {}},
+    {"restir: spatital radius", PT_INT, POFF(restir_spatial_radius), false, {}},
+    {"restir: spatial bias correction", PT_OPTION, POFF(restir_spatial_bias), false, {"none", "basic", "raytraced"}},
+    {"restir: shade visibility", PT_BOOL, POFF(restir_shade_visibility), false, {}},
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
     {"overlap camera rays", PT_BOOL, POFF(overlap_camera_rays), false, {}},
+    {"camera rays: frustum packets", PT_BOOL, POFF(packet_camera_rays), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
     {"quirk: 16-bit N*N", PT_BOOL, POFF(quirk_n16_wrap), false, {}},
@@ -365,6 +388,7 @@ void free_frame_state(mq_ctx* c) {
     for (auto& b : c->d_out) dev_free(b);
     dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
+    dev_free(c->d_restir_pong); dev_free(c->d_restir_prev); dev_free(c->d_restir_prev_gb);
     dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
     dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0;
     dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); c->shaded_valid[0] = c->shaded_valid[1] = false;
@@ -385,7 +409,7 @@ size_t queue_entries_needed(const mq_ctx* c) {
     return segs + segs / 8 + (size_t)MQ_SHARDS * 64 * 4;
 }
 
-const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8, 16, 4, 16, 4, 16};
+const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8, 16, 4, 16, 4, 16, 16, 8, 64};
 
 void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     memset(d, 0, sizeof *d);
@@ -474,6 +498,7 @@ int mq_set_property(mq_ctx* c, const char* key, double value) {
     if (d->type == PT_OPTION) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
     bool changed = prop_set(c->props, *d, value);
     if (changed) c->params_dirty = true;
+    if (changed && !strncmp(key, "restir: ", 8)) c->restir_seeded = false; // "recreate pipeline": a new seed if they are randomized (renderer_restir.cpp:152-158)
     if (changed && d->reconnect) { c->connected = false; return 1; } // NEEDS_RECONNECT, render_mcpg.cpp:567-575
     return 0;
 }
@@ -856,6 +881,10 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_post_prev_gb, (size_t)w * h * 16))) return r;
     for (int k = 0; k < 2; k++) { if ((r = dev_alloc(c, c->d_post_prev_out[k], (size_t)w * h * 16))) return r; if ((r = dev_alloc(c, c->d_post_prev_hist[k], (size_t)w * h * 4))) return r; }
     c->post_first = true;
+    if ((r = dev_alloc(c, c->d_restir_pong, (size_t)w * h * 64))) return r;
+    if ((r = dev_alloc(c, c->d_restir_prev, (size_t)w * h * 64))) return r;
+    if ((r = dev_alloc(c, c->d_restir_prev_gb, (size_t)w * h * 16))) return r;
+    c->restir_iteration = 0; c->restir_seeded = false;
     c->dist_mc_n = (uint32_t)(d.state_bytes_volume_distancemc / sizeof(MqDistMC));
     if ((r = dev_alloc(c, c->d_dist_mc, d.state_bytes_volume_distancemc))) return r;
     c->iteration = 0; c->connected = true; c->params_dirty = true; c->volume_outputs_zero = true; // outputs were cleared above
@@ -1050,7 +1079,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         return MQ_OK;
     };
     // a shared-stack entry per level with pending siblings, +1 for the per-frame root waiting at the bottom
-    const bool packet = (int)std::max(c->s_depth, c->d_depth) + 2 <= mq_packet_stack_entries() && !getenv("MQ_DEBUG_NO_PACKET");
+    const bool packet = c->props.packet_camera_rays && (int)std::max(c->s_depth, c->d_depth) + 2 <= mq_packet_stack_entries();
     if (!c->count_enabled) // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
         for (int k = 0; k < S; k++) {
             e = mq_launch_primary_trace(c->scene, c->params, FS[k], packet, overlap_pt ? c->grid_frame[1] : sub_grid(1), overlap_pt ? c->pt_stream : st(k));
@@ -1255,6 +1284,60 @@ int mq_debug_state_write(mq_ctx* c, int which, const void* src, size_t bytes) {
     if (c->iteration == 0) return fail(c, MQ_ESTATE, "process one frame before writing state (the first frame zeroes it)");
     HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(b->p, src, bytes, hipMemcpyHostToDevice));
+    return MQ_OK;
+}
+
+// ---- ReSTIR DI node (mq_restir.h): RendererRESTIR::process, src/render_restir/renderer_restir.cpp:129-251 ----------
+int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
+    if (!c || !u) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    if (!c->connected) return fail(c, MQ_ESTATE, "mq_restir_process before mq_connect");
+    if (!c->committed) return fail(c, MQ_ESTATE, "mq_restir_process before mq_scene_commit");
+    if (c->world != 1) return fail(c, MQ_ESTATE, "the ReSTIR node needs the whole image on this context (partition 0 of 1)");
+    hipStream_t s = (hipStream_t)stream;
+    c->last_stream = s;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->params_dirty) props_to_params(c);
+    const MqProps& q = c->props;
+    if (!c->restir_seeded) { // pipeline (re)creation, renderer_restir.cpp:152-158
+        if (q.restir_randomize_seed) { std::random_device dev; std::mt19937 rng(dev()); c->props.restir_seed = (uint32_t)rng(); }
+        c->restir_seed_in_use = c->props.restir_seed; c->restir_seeded = true;
+    }
+    MqRestirParams R;
+    R.spp = q.restir_spp; R.seed = c->restir_seed_in_use; R.visibility_shade = q.restir_shade_visibility;
+    R.temporal_normal_reject_cos = (float)std::cos((double)q.restir_temporal_normal_angle); R.temporal_depth_reject = q.restir_temporal_depth;
+    R.spatial_normal_reject_cos = (float)std::cos((double)q.restir_spatial_normal_angle); R.spatial_depth_reject = q.restir_spatial_depth;
+    R.temporal_clamp_m = q.restir_temporal_clamp_m; R.spatial_radius = q.restir_spatial_radius; R.temporal_bias_correction = q.restir_temporal_bias; R.spatial_bias_correction = q.restir_spatial_bias;
+    R.boiling_filter_strength = q.restir_boiling; R.spatial_reuse_iterations = std::max(q.restir_spatial_iterations, 1); R.apply_mv = q.restir_apply_mv ? 1 : 0; // renderer_restir.cpp:175
+    MqRestirFrame F; memset(&F, 0, sizeof F);
+    F.u = *u; F.W = c->W; F.H = c->H; F.tiles_x = c->tiles_x; F.n_tiles = c->tiles_x * c->tiles_y;
+    F.hits = (const uint32_t*)c->d_out[MQ_OUT_HITS].p; F.gbuffer = (const uint4*)c->d_out[MQ_OUT_GBUFFER].p; F.prev_gbuffer = (const uint4*)c->d_restir_prev_gb.p;
+    F.mv = (const uint32_t*)c->d_out[MQ_OUT_GB_MV].p; F.prev_reservoirs = (const uint4*)c->d_restir_prev.p;
+    F.irradiance = (float4*)c->d_out[MQ_OUT_RESTIR_IRRADIANCE].p; F.moments = (float2*)c->d_out[MQ_OUT_RESTIR_MOMENTS].p;
+    F.stack_spill = (unsigned long long*)c->d_spill.p;
+    uint4* const out = (uint4*)c->d_out[MQ_OUT_RESTIR_RESERVOIRS].p; uint4* const pong = (uint4*)c->d_restir_pong.p;
+    const int grid = std::max(1, c->cu_count) * 2; // 2 blocks per CU at the shading kernels' register budget; the spill area holds grid_blocks >= this
+    const size_t px = (size_t)c->W * c->H;
+    int e = 0;
+    if (!render) { // renderer_restir.cpp:189-197: the clear pass writes set (1): `reservoirs` = the graph output
+        F.res_a = out; F.res_read = pong;
+        e = mq_launch_restir(c->scene, c->params, R, F, 4, grid, s);
+        if (e) return fail(c, MQ_EHIP, std::string("restir clear launch: ") + hipGetErrorString((hipError_t)e));
+    } else {
+        // the ping-pong of renderer_restir.cpp:136-146,213-250: the last writer before the shade pass is the graph output
+        const bool spatial = q.restir_spatial_iterations > 0;
+        F.res_a = spatial ? pong : out; F.res_read = spatial ? out : pong;
+        e = mq_launch_restir(c->scene, c->params, R, F, 0, grid, s);
+        if (!e && q.restir_temporal_reuse && c->restir_iteration > 0) e = mq_launch_restir(c->scene, c->params, R, F, 1, grid, s);
+        if (!e && spatial) { F.res_a = out; F.res_read = pong; e = mq_launch_restir(c->scene, c->params, R, F, 2, grid, s); }
+        F.res_a = out; F.res_read = pong;
+        if (!e) e = mq_launch_restir(c->scene, c->params, R, F, 3, grid, s);
+        if (e) return fail(c, MQ_EHIP, std::string("restir launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    // the graph's delay-1 inputs of the next frame: "reservoirs" and "prev_gbuffer" (renderer_restir.hpp:73-74,86-87)
+    HIPCHK(c, hipMemcpyAsync(c->d_restir_prev.p, out, px * 64, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_restir_prev_gb.p, c->d_out[MQ_OUT_GBUFFER].p, px * 16, hipMemcpyDeviceToDevice, s));
+    c->restir_iteration++;
     return MQ_OK;
 }
 

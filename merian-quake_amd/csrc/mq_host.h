@@ -75,6 +75,7 @@ struct MqProps {
     bool freeze_learning = false; // test hook, not a reference property
     bool log_learning = false;    // test hook, not a reference property
     bool overlap_camera_rays = false; // scheduling of this build: the camera rays of frame n + 1 traced beside the kernels of frame n (measured: no gain)
+    bool packet_camera_rays = false;  // scheduling of this build: camera rays as one frustum packet per 8x8 tile (bit-identical; measured slower than the per-lane walk)
     int pipelines = 1; // scheduling of this build, not a reference property: sub-pipelines per frame (mq_api.cpp mq_process)
     bool sequential_update_pass = false; // test hook: the update pass in the reference's dispatch order, one slot after the other
     // post chain: the "accum" and "volume accum" nodes of res/default_config.json (header defaults = its values)
@@ -82,6 +83,12 @@ struct MqProps {
     bool accum_enable_mv = true, accum_reuse_border = true;
     float vaccum_alpha = 0.902f, vaccum_max_history = INFINITY, vaccum_normal_threshold = 3.1415927410125732f, vaccum_depth_threshold = 0.28402701020240784f;
     bool vaccum_enable_mv = true, vaccum_reuse_border = true;
+    // ReSTIR DI node, src/render_restir/renderer_restir.hpp:108-127 (normal thresholds as the angles the UI shows, renderer_restir.cpp:276-279,303-306)
+    int restir_spp = 1; uint32_t restir_seed = 0; bool restir_randomize_seed = true;
+    bool restir_temporal_reuse = false; float restir_temporal_normal_angle = 0.28379410920832787f /* acos(0.96) */, restir_temporal_depth = 0.1f;
+    int restir_temporal_clamp_m = 32 * 20, restir_temporal_bias = 0; float restir_boiling = 0.0f; bool restir_apply_mv = false;
+    int restir_spatial_iterations = 0; float restir_spatial_normal_angle = 0.28379410920832787f, restir_spatial_depth = 0.1f;
+    int restir_spatial_radius = 30, restir_spatial_bias = 0; bool restir_shade_visibility = false;
     // named quirk switches: on = what the reference's shaders compute, off = the evident intent
     bool quirk_lc_max_wo_p = true; // mcpg.comp:170 `max(wo_p, 10)`
     bool quirk_n16_wrap = true;    // mc.glsl:26 `N * N` on a uint16_t (grid.h:19): wraps, 0 at N = 256 / 512 / 768 / 1024

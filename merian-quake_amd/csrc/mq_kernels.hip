@@ -374,6 +374,32 @@ MQ_DEV void traverse(const MqSceneDev& sc, f3 o, f3 d, RayHit& hit, uint2* stk, 
     hit = t.hit;
 }
 
+// closest hit within (tmin, tmax): visibility rays (trace_visibility_ray_init, raytrace.glsl:66-80)
+template <bool COUNT>
+MQ_DEV void traverse_range(const MqSceneDev& sc, f3 o, f3 d, float tmin, float tmax, RayHit& hit, uint2* stk, unsigned long long* spill, Ctr& ctr) {
+    Trav t;
+    trav_init(t, o, d);
+    t.tlim = trav_limit(tmax);
+    trav_defer(sc, t, stk);
+    if (sc.n_nodes != 0) for (;;) {
+        trav_node<COUNT>(sc, t, stk, spill, ctr);
+        while (t.tmask) { // trav_tri with the ray's own interval
+            const uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
+            t.tmask &= t.tmask - 1u;
+            const uint4* tp = (const uint4*)(sc.tris + (t.tbase + k));
+            const uint4 a = tp[0], b = tp[1], c = tp[2];
+            float tt = 0.0f, u = 0.0f, v = 0.0f;
+            bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
+                                    F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), tt, u, v);
+            accept = accept && tt > tmin && tt < tmax && (tt < t.hit.t || (tt == t.hit.t && c.y < t.best_key));
+            if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, t.tbase + k, u, v);
+            if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = t.tbase + k; t.best_key = c.y; t.tlim = trav_limit(tt); }
+        }
+        if (trav_next(t, stk, spill)) break;
+    }
+    hit = t.hit;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sky + trace_ray shading (raytrace.glsl:25-65,156-311)
 // ------------------------------------------------------------------------------------------------
@@ -2087,6 +2113,8 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
     case 16: { f4 x = tex_sample(sc, (uint32_t)a[0], a[1], a[2]); o[0] = x.r; o[1] = x.g; o[2] = x.b; o[3] = x.a; break; }
     }
 }
+
+#include "mq_restir.h"
 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage; used by mq_api.cpp)

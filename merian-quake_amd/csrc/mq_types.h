@@ -239,3 +239,30 @@ struct MqFrame {
     // dynamic LDS of the shading kernels: 8-byte rows of 64 lanes per wave (lobe storage: 3 rows per Markov-chain sample)
     uint32_t lds_rows2;
 };
+
+// ---- ReSTIR DI node (mq_restir.h) ----
+struct MqRestirParams { // the specialisation constants of renderer_restir.cpp:163-176
+    int32_t spp;
+    uint32_t seed;
+    int32_t visibility_shade;
+    float temporal_normal_reject_cos, temporal_depth_reject, spatial_normal_reject_cos, spatial_depth_reject;
+    int32_t temporal_clamp_m, spatial_radius, temporal_bias_correction, spatial_bias_correction;
+    float boiling_filter_strength;
+    int32_t spatial_reuse_iterations, apply_mv;
+};
+
+struct MqRestirFrame {
+    mq_uniform u;
+    uint32_t W, H, tiles_x, n_tiles;
+    const uint32_t* hits;      // gbuffer "hits" (CompressedHit, 10 dwords per pixel)
+    const uint4* gbuffer;      // gbuffer "gbuffer"
+    const uint4* prev_gbuffer; // the same, one frame ago
+    const uint32_t* mv;        // gbuffer "mv" (RG16F)
+    const uint4* prev_reservoirs; // "reservoirs" output of the previous frame
+    uint4* res_a;              // binding 1 of the ping-pong set: `reservoirs` (read-write)
+    const uint4* res_read;     // binding 0: `reservoirs_spatial_read`
+    float4* irradiance;        // RGBA32F
+    float2* moments;           // RG32F
+    unsigned long long* stack_spill;
+};
+

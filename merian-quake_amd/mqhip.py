@@ -19,7 +19,8 @@ MQ_MAX_GEOMETRIES = 16
 MQ_GEO_OPAQUE, MQ_GEO_STATIC = 1, 2
 MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
 (OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_VOLUME, OUT_VOLUME_DEPTH,
- OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_DEBUG, OUT_ACCUM, OUT_ACCUM_HISTORY, OUT_VOLUME_ACCUM, OUT_VOLUME_ACCUM_HISTORY, OUT_FINAL, OUT_COUNT) = range(18)
+ OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_DEBUG, OUT_ACCUM, OUT_ACCUM_HISTORY, OUT_VOLUME_ACCUM, OUT_VOLUME_ACCUM_HISTORY, OUT_FINAL,
+ OUT_RESTIR_IRRADIANCE, OUT_RESTIR_MOMENTS, OUT_RESTIR_RESERVOIRS, OUT_COUNT) = range(21)
 MQ_ENODEVICE = -2
 
 EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),
@@ -125,6 +126,7 @@ def load_library(path=None):
         "mq_debug_state_write": (i32, [P, i32, vp, sz]),
         "mq_debug_section_clocks": (i32, [P, C.POINTER(C.c_uint64), i32, i32]),
         "mq_post_process": (i32, [P, vp]),
+        "mq_restir_process": (i32, [P, C.POINTER(Uniform), i32, vp]),
         "mq_post_clear": (i32, [P]),
         "mq_debug_learn_log_read": (i32, [P, vp, sz, C.POINTER(sz)]),
         "mq_debug_apply_updates": (i32, [P, vp, u32, C.POINTER(Uniform)]),
@@ -373,6 +375,9 @@ class Context:
     def state_write(self, which, a):
         a = np.ascontiguousarray(a, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE)[which])
         self._chk(self.lib.mq_debug_state_write(self.h, which, a.ctypes.data, a.nbytes))
+
+    def restir_process(self, uniform, render=True, stream=None):
+        self._chk(self.lib.mq_restir_process(self.h, C.byref(uniform), 1 if render else 0, stream))
 
     def post_process(self, stream=None):
         self._chk(self.lib.mq_post_process(self.h, stream))

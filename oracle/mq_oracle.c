@@ -106,6 +106,8 @@ struct orc_ctx {
     /* learning-write log (params.log_learning) and the touch list of orc_debug_apply_updates */
     uint32_t* llog; size_t llog_cap, llog_n;
     uint32_t* touch; size_t touch_cap, touch_n;
+    /* ReSTIR DI node */
+    uint8_t* rs_out; uint8_t* rs_pong; uint8_t* rs_prev; gbuf_t* rs_prev_gb; float* rs_irr; float* rs_mom; uint64_t rs_iteration;
     /* post chain */
     float post_par[2][6];
     float* post_out[2]; float* post_hist[2]; float* post_prev_out[2]; float* post_prev_hist[2]; gbuf_t* post_prev_gb; float* post_final;
@@ -162,6 +164,8 @@ orc_ctx* orc_create(const orc_params_t* p) {
 static void free_state(orc_ctx* c) {
     for (int k = 0; k < 2; k++) { free(c->post_out[k]); free(c->post_hist[k]); free(c->post_prev_out[k]); free(c->post_prev_hist[k]); c->post_out[k] = c->post_hist[k] = c->post_prev_out[k] = c->post_prev_hist[k] = NULL; }
     free(c->post_prev_gb); free(c->post_final); c->post_prev_gb = NULL; c->post_final = NULL;
+    free(c->rs_out); free(c->rs_pong); free(c->rs_prev); free(c->rs_prev_gb); free(c->rs_irr); free(c->rs_mom);
+    c->rs_out = c->rs_pong = c->rs_prev = NULL; c->rs_prev_gb = NULL; c->rs_irr = c->rs_mom = NULL;
     free(c->llog); c->llog = NULL; c->llog_cap = c->llog_n = 0;
     free(c->mc); free(c->lc); free(c->upd_count); free(c->upd_rec); free(c->upd_pool); free(c->upd_touched);
     free(c->irradiance); free(c->gb_albedo); free(c->gb_irr); free(c->gb_mv); free(c->gbuffer); free(c->hits);
@@ -384,6 +388,16 @@ static int anyhit_confirm(const orc_ctx* c, uint32_t key, float u, float v) {
     return tex_gather_alpha_r(c, e->texnum_alpha & 0xfffu, s, t) >= ALPHA_THRESHOLD;
 }
 
+static inline void consider_range(const orc_ctx* c, const tri_t* tr, v3 o, v3 d, float tmin, float tmax, rayhit_t* best, orc_counters_t* ctr) {
+    float t, u, v;
+    ctr->tris++;
+    if (!tri_isect(o, d, tr->v0, tr->v1, tr->v2, &t, &u, &v)) return;
+    if (!(t < tmax) || !(t > tmin)) return;
+    if (t < best->t || (t == best->t && tr->key < best->key)) {
+        if (!tr->opaque && !anyhit_confirm(c, tr->key, u, v)) return;
+        best->t = t; best->u = u; best->v = v; best->key = tr->key;
+    }
+}
 static inline void consider(const orc_ctx* c, const tri_t* tr, v3 o, v3 d, float tmax, rayhit_t* best, orc_counters_t* ctr) {
     float t, u, v;
     ctr->tris++;
@@ -523,6 +537,8 @@ int orc_connect(orc_ctx* c, uint32_t w, uint32_t h) {
     { uint32_t gw = c->p.distance_mc_grid_width > 0 ? (uint32_t)c->p.distance_mc_grid_width : 25u; /* render_mcpg.cpp:80-82 */
       c->dist_mc_n = (w / gw + 2) * (h / gw + 2) * 10u; c->dist_mc = (distmc_t*)calloc(c->dist_mc_n, sizeof(distmc_t)); }
     for (int k = 0; k < 2; k++) { c->post_out[k] = (float*)calloc(px, 16); c->post_hist[k] = (float*)calloc(px, 4); c->post_prev_out[k] = (float*)calloc(px, 16); c->post_prev_hist[k] = (float*)calloc(px, 4); }
+    c->rs_out = (uint8_t*)calloc(px, 64); c->rs_pong = (uint8_t*)calloc(px, 64); c->rs_prev = (uint8_t*)calloc(px, 64); c->rs_prev_gb = (gbuf_t*)calloc(px, sizeof(gbuf_t));
+    c->rs_irr = (float*)calloc(px, 16); c->rs_mom = (float*)calloc(px, 8); c->rs_iteration = 0;
     c->post_prev_gb = (gbuf_t*)calloc(px, sizeof(gbuf_t)); c->post_final = (float*)calloc(px, 16); c->post_first = 1; c->volume_ran = 0;
     c->iteration = 0;
     if (!c->mc || !c->lc || !c->upd_count || !c->upd_rec || !c->upd_pool || !c->irradiance || !c->hits) return -1;
@@ -1431,6 +1447,264 @@ int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
     } else { memset(c->volume, 0, px * 16); c->volume_ran = 0; }
     c->iteration++;
     return 0;
+}
+
+/* ---------------------------------------------------------------- ReSTIR DI node */
+
+/* ReSTIRDIReservoir, restir_di_reservoir.glsl.h:8-27: 64 bytes in the scalar layout */
+typedef struct { uint32_t M; float w, p_target; float pos[3], normal[3], mv[3]; float T; uint16_t rad[3]; uint16_t _pad; uint32_t flags; } reservoir_t;
+static reservoir_t res_init(void) { reservoir_t r; memset(&r, 0, sizeof r); return r; }
+static inline v3 a3(const float* p) { return V3(p[0], p[1], p[2]); }
+static inline void s3(float* p, v3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+static void res_discard(reservoir_t* r) { r->w = 0.0f; r->flags = 0; r->rad[0] = r->rad[1] = r->rad[2] = 0; } /* restir_di.glsl:54-58 */
+static void res_take_sample(reservoir_t* r, const reservoir_t* x) { memcpy(r->pos, x->pos, 36); r->T = x->T; memcpy(r->rad, x->rad, 6); r->flags = x->flags; }
+/* restir_di_common.glsl:7-18.  DEFINED: pow(d, 2) = d * d; yuv_luminance_f16 = luminance of the half radiance, rounded to half */
+static float restir_target_pdf(const reservoir_t* y, const hit_t* surface) {
+    v3 dv = vsub(a3(y->pos), surface->pos);
+    v3 wo = vnormalize(dv);
+    float wodotn = vdot(wo, surface->normal);
+    if (wodotn <= 0.0f) return 0.0f;
+    float bsdf = orc_bsdf_times_wodotn(surface->wi, wo, surface->normal, orc_roughness_to_alpha(surface->roughness), 0.02f);
+    float dist = vlen(dv);
+    return ((omax(vdot(a3(y->normal), vneg(wo)), 0.0f) / (dist * dist)) * bsdf) * orc_rh(orc_luminance(h3(y->rad)));
+}
+static int res_add_sample(tls_t* tl, reservoir_t* r, const reservoir_t* x, float p_sample, float p_target) { /* restir_di.glsl:69-88 */
+    float w = p_target / p_sample;
+    r->w += w; r->M += 1;
+    if (X(tl) * r->w < w) { r->p_target = p_target; res_take_sample(r, x); return 1; }
+    return 0;
+}
+static int res_combine_finalized(tls_t* tl, reservoir_t* r, const reservoir_t* o, float p_target_x_y) { /* restir_di.glsl:125-141 */
+    r->M += o->M;
+    float w = (p_target_x_y * o->w) * (float)o->M;
+    r->w += w;
+    if (X(tl) * r->w < w) { r->p_target = p_target_x_y; res_take_sample(r, o); return 1; }
+    return 0;
+}
+static void res_finalize(reservoir_t* r) { float den = (float)r->M * r->p_target; r->w = den > 0.0f ? r->w / den : 0.0f; }                       /* :146-149 */
+static void res_finalize_custom(reservoir_t* r, float num, float den) { den *= r->p_target; r->w = den > 0.0f ? (r->w * num) / den : 0.0f; } /* :153-156 */
+/* DEFINED (merian-shaders/reprojection.glsl is absent): normals within the threshold, depths within a fraction of the larger one */
+static int reprojection_valid(v3 n, v3 pn, float cos_reject, float z, float vel_z, float pz, float depth_reject) {
+    float ze = z + vel_z;
+    return vdot(n, pn) >= cos_reject && fabsf(ze - pz) <= depth_reject * omax(ze, pz);
+}
+/* trace_visibility, raytrace.glsl:66-150: tmin 1e-3, tmax |to - from| - 2e-3; a sky surface in between does not occlude */
+static int trace_visibility(tls_t* tl, v3 from, v3 to) {
+    const orc_ctx* c = tl->c;
+    v3 wo = vsub(to, from);
+    float len = vlen(wo);
+    v3 d = vnormalize(wo);
+    float tmin = 1e-3f, tmax = omax(1e-3f, len - 2.0f * 1e-3f);
+    rayhit_t best; best.key = 0xffffffffu; best.t = INFINITY; best.u = best.v = 0.0f;
+    tl->ctr.rays++;
+    if (!c->accel || !c->nodes) { for (uint32_t i = 0; i < c->n_tris; i++) consider_range(c, &c->tris[i], from, d, tmin, tmax, &best, &tl->ctr); }
+    else {
+        v3 id;
+        id.x = 1.0f / (fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f));
+        id.y = 1.0f / (fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f));
+        id.z = 1.0f / (fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f));
+        uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+        while (sp) {
+            const bnode_t* n = &c->nodes[stack[--sp]]; float tn;
+            if (!slab(n, from, id, omin(best.t, tmax), &tn)) continue;
+            if (n->count) { for (uint32_t i = 0; i < n->count; i++) consider_range(c, &c->tris[n->left + i], from, d, tmin, tmax, &best, &tl->ctr); continue; }
+            if (sp < 120) { stack[sp++] = n->left; stack[sp++] = n->left + 1; }
+        }
+    }
+    if (best.key == 0xffffffffu) return 1;
+    return (ext_of(c, best.key)->texnum_fb_flags >> 12) == MAT_FLAGS_SKY;
+}
+
+typedef struct { orc_ctx* c; const orc_restir_params_t* r; int pass, tid, nthreads; uint8_t* res_a; const uint8_t* res_read; orc_counters_t ctr; } rjob_t;
+#define RES(buf, i) ((reservoir_t*)((buf) + 64 * (size_t)(i)))
+static void restir_generate_pixel(tls_t* tl, const rjob_t* j, uint32_t px, uint32_t py) { /* restir_di_generate_samples_bsdf.comp:23-62 */
+    orc_ctx* c = j->c; const orc_restir_params_t* R = j->r;
+    size_t idx = (size_t)py * c->W + px;
+    tl->rng = orc_pcg4d16(px, py, c->u.frame * 4u + 0u, R->seed);
+    reservoir_t r = res_init();
+    hit_t first; decompress_hit(&c->hits[idx], &first);
+    v3 sun = V3(c->p.sun_color[0], c->p.sun_color[1], c->p.sun_color[2]);
+    if (first.albedo.x >= 1e-7f || first.albedo.y >= 1e-7f || first.albedo.z >= 1e-7f)
+        for (int s = 0; s < R->spp; s++) {
+            float alpha = orc_roughness_to_alpha(first.roughness);
+            float x0 = X(tl), x1 = X(tl), x2 = X(tl);
+            v3 wo = orc_bsdf_sample(first.wi, first.normal, alpha, x0, x1, x2);
+            float wodotn = vdot(wo, first.normal);
+            if (vdot(wo, orc_decode_normal(first.enc_geonormal)) <= 1e-3f || wodotn <= 1e-3f) continue;
+            hit_t next; memset(&next, 0, sizeof next);
+            next.wi = wo; next.pos = vsub(first.pos, vscale(first.wi, 1e-3f));
+            v3 incident = V3(0, 0, 0), throughput = V3(1, 1, 1);
+            trace_ray(tl, &throughput, &incident, &next, sun, NULL);
+            float dist = vlen(vsub(next.pos, first.pos));
+            float geo = omax(vdot(next.normal, vneg(wo)), 0.0f) / (dist * dist);
+            reservoir_t x = res_init();
+            s3(x.pos, next.pos); s3(x.normal, next.normal); s3(x.mv, vscale(vsub(next.pos, next.prev_pos), 1.0f / c->u.cam_w[3])); x.T = c->u.cl_time;
+            x.rad[0] = orc_f2h(incident.x); x.rad[1] = orc_f2h(incident.y); x.rad[2] = orc_f2h(incident.z); x.flags = 1u;
+            res_add_sample(tl, &r, &x, geo * orc_bsdf_pdf(first.wi, wo, first.normal, alpha), restir_target_pdf(&x, &first));
+        }
+    res_finalize(&r);
+    *RES(j->res_a, idx) = r;
+}
+/* restir_di_temporal_reuse.comp:71-146 for one 8x8 tile (the boiling filter, :37-69, averages over the workgroup: lane order) */
+static void restir_temporal_tile(tls_t* tl, const rjob_t* j, uint32_t tx, uint32_t ty) {
+    orc_ctx* c = j->c; const orc_restir_params_t* R = j->r;
+    reservoir_t rr[64]; int active[64];
+    for (int lane = 0; lane < 64; lane++) {
+        uint32_t px = tx * 8u + ((uint32_t)lane & 7u), py = ty * 8u + ((uint32_t)lane >> 3);
+        active[lane] = px < c->W && py < c->H;
+        rr[lane] = res_init();
+        if (!active[lane]) continue;
+        size_t idx = (size_t)py * c->W + px;
+        reservoir_t* r = &rr[lane];
+        tl->rng = orc_pcg4d16(px, py, c->u.frame * 4u + 1u, R->seed);
+        const reservoir_t cur = *RES(j->res_a, idx);
+        res_combine_finalized(tl, r, &cur, cur.p_target);
+        float qx = floorf(((float)px + orc_h2f(c->gb_mv[2 * idx])) + 0.5f), qy = floorf(((float)py + orc_h2f(c->gb_mv[2 * idx + 1])) + 0.5f);
+        active[lane] = qx >= 0.0f && qy >= 0.0f && qx < (float)c->W && qy < (float)c->H;
+        if (!active[lane]) continue;
+        size_t q = (size_t)(uint32_t)qy * c->W + (uint32_t)qx;
+        const gbuf_t* g = &c->gbuffer[idx]; const gbuf_t* pg = &c->rs_prev_gb[q];
+        active[lane] = reprojection_valid(orc_decode_normal(g->enc_normal), orc_decode_normal(pg->enc_normal), R->temporal_normal_reject_cos, g->linear_z, g->vel_z, pg->linear_z, R->temporal_depth_reject);
+        if (!active[lane]) continue;
+        hit_t center; decompress_hit(&c->hits[idx], &center);
+        reservoir_t prev = *RES(c->rs_prev, q);
+        if (R->apply_mv == 1) { s3(prev.pos, vadd(a3(prev.pos), vscale(a3(prev.mv), c->u.cl_time - prev.T))); prev.T = c->u.cl_time; }
+        if (R->temporal_clamp_m > 0) prev.M = prev.M < (uint32_t)R->temporal_clamp_m ? prev.M : (uint32_t)R->temporal_clamp_m;
+        int selected_prev = res_combine_finalized(tl, r, &prev, restir_target_pdf(&prev, &center));
+        if (R->temporal_bias_correction == 0) res_finalize(r);
+        else { /* :110-138 */
+            float pi = r->p_target, pi_sum = r->p_target * (float)cur.M;
+            hit_t psurf; decompress_hit(&c->hits[q], &psurf); /* surface_at(prev_pixel): this frame's record at that pixel, as the reference reads it */
+            float temporal_p = restir_target_pdf(r, &psurf);
+            if (temporal_p > 0.0f) {
+                if (R->temporal_bias_correction == 2 && !trace_visibility(tl, center.pos, a3(r->pos))) temporal_p = 0.0f;
+                if (R->temporal_bias_correction == 3) temporal_p = 0.0f;
+            }
+            pi = selected_prev ? temporal_p : pi;
+            pi_sum += temporal_p * (float)prev.M;
+            res_finalize_custom(r, pi, pi_sum);
+        }
+    }
+    if (R->boiling_filter_strength > 1e-6f) {
+        float mult = 10.0f / R->boiling_filter_strength - 9.0f, sum = 0.0f; uint32_t count = 0;
+        for (int lane = 0; lane < 64; lane++) if (active[lane]) { sum += rr[lane].w; count += rr[lane].w > 0.0f ? 1u : 0u; }
+        float avg = count > 0 ? sum / (float)count : 0.0f;
+        for (int lane = 0; lane < 64; lane++) if (active[lane] && rr[lane].w > avg * mult) res_discard(&rr[lane]);
+    }
+    for (int lane = 0; lane < 64; lane++) if (active[lane]) {
+        uint32_t px = tx * 8u + ((uint32_t)lane & 7u), py = ty * 8u + ((uint32_t)lane >> 3);
+        *RES(j->res_a, (size_t)py * c->W + px) = rr[lane];
+    }
+}
+static void restir_spatial_pixel(tls_t* tl, const rjob_t* j, uint32_t px, uint32_t py) { /* restir_di_spatial_reuse.comp:26-101 */
+    orc_ctx* c = j->c; const orc_restir_params_t* R = j->r;
+    size_t idx = (size_t)py * c->W + px;
+    int NI = R->spatial_reuse_iterations < 1 ? 1 : (R->spatial_reuse_iterations > 7 ? 7 : R->spatial_reuse_iterations);
+    tl->rng = orc_pcg4d16(px, py, c->u.frame * 4u + 2u, R->seed);
+    reservoir_t r = res_init();
+    const reservoir_t cur = *RES(j->res_read, idx);
+    res_combine_finalized(tl, &r, &cur, cur.p_target);
+    hit_t center; decompress_hit(&c->hits[idx], &center);
+    const gbuf_t* g = &c->gbuffer[idx];
+    int selected = -1; uint32_t nq[7];
+    for (int i = 0; i < NI; i++) {
+        float x0 = X(tl), x1 = X(tl);
+        float nx = floorf(((float)px + (float)R->spatial_radius * (2.0f * x0 - 1.0f)) + 0.5f), ny = floorf(((float)py + (float)R->spatial_radius * (2.0f * x1 - 1.0f)) + 0.5f);
+        nq[i] = 0xffffffffu;
+        if (!(nx >= 0.0f && ny >= 0.0f && nx < (float)c->W && ny < (float)c->H)) continue;
+        uint32_t q = (uint32_t)ny * c->W + (uint32_t)nx;
+        const gbuf_t* ng = &c->gbuffer[q];
+        if (!reprojection_valid(orc_decode_normal(g->enc_normal), orc_decode_normal(ng->enc_normal), R->spatial_normal_reject_cos, g->linear_z, g->vel_z, ng->linear_z, R->spatial_depth_reject)) continue;
+        nq[i] = q;
+        const reservoir_t nb = *RES(j->res_read, q);
+        if (res_combine_finalized(tl, &r, &nb, restir_target_pdf(&nb, &center))) selected = i;
+    }
+    if (R->spatial_bias_correction == 0) res_finalize(&r);
+    else { /* :75-97 */
+        float pi = r.p_target, pi_sum = r.p_target * (float)cur.M;
+        for (int i = 0; i < NI; i++) {
+            if (nq[i] == 0xffffffffu) continue;
+            hit_t ns; decompress_hit(&c->hits[nq[i]], &ns);
+            float spatial_p = restir_target_pdf(&r, &ns);
+            if (R->spatial_bias_correction == 2 && spatial_p > 0.0f && !trace_visibility(tl, ns.pos, a3(r.pos))) spatial_p = 0.0f;
+            pi = selected == i ? spatial_p : pi;
+            pi_sum += spatial_p * (float)RES(j->res_read, nq[i])->M;
+        }
+        res_finalize_custom(&r, pi, pi_sum);
+    }
+    *RES(j->res_a, idx) = r;
+}
+static void restir_shade_pixel(tls_t* tl, const rjob_t* j, uint32_t px, uint32_t py) { /* restir_di_shade.comp:21-62 */
+    orc_ctx* c = j->c; const orc_restir_params_t* R = j->r;
+    size_t idx = (size_t)py * c->W + px;
+    reservoir_t r = *RES(j->res_a, idx);
+    v3 irr = V3(0, 0, 0);
+    v3 sun = V3(c->p.sun_color[0], c->p.sun_color[1], c->p.sun_color[2]);
+    if (r.flags & 1u) {
+        hit_t first; decompress_hit(&c->hits[idx], &first);
+        v3 dv = vsub(a3(r.pos), first.pos);
+        v3 wo = vnormalize(dv);
+        hit_t next; memset(&next, 0, sizeof next);
+        next.wi = wo; next.pos = vsub(first.pos, vscale(first.wi, 1e-3f));
+        v3 incident = V3(0, 0, 0), throughput = V3(1, 1, 1);
+        trace_ray(tl, &throughput, &incident, &next, sun, NULL);
+        float d_sample = vlen(dv), d_hit = vlen(vsub(first.pos, next.pos));
+        if (R->visibility_shade && fabsf(d_sample - d_hit) / omax(d_sample, d_hit) > 0.1f) { res_discard(&r); *RES(j->res_a, idx) = r; }
+        float bsdf = orc_bsdf_times_wodotn(first.wi, wo, first.normal, orc_roughness_to_alpha(first.roughness), 0.02f);
+        if (isfinite(r.w)) irr = vscale(vscale(vscale(h3(r.rad), bsdf), r.w), omax(vdot(a3(r.normal), vneg(wo)), 0.0f) / (d_sample * d_sample));
+    }
+    float* o = c->rs_irr + 4 * idx; o[0] = irr.x; o[1] = irr.y; o[2] = irr.z; o[3] = 1.0f;
+    float l = orc_luminance(irr);
+    c->rs_mom[2 * idx] = l; c->rs_mom[2 * idx + 1] = l * l;
+}
+static void* restir_worker(void* arg) {
+    rjob_t* j = (rjob_t*)arg; orc_ctx* c = j->c;
+    tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
+    const uint32_t tiles_x = (c->W + 7) / 8, tiles_y = (c->H + 7) / 8;
+    for (uint32_t t = (uint32_t)j->tid; t < tiles_x * tiles_y; t += (uint32_t)j->nthreads) {
+        uint32_t tx = t % tiles_x, ty = t / tiles_x;
+        if (j->pass == 1) { restir_temporal_tile(&tl, j, tx, ty); continue; }
+        for (int lane = 0; lane < 64; lane++) {
+            uint32_t px = tx * 8u + ((uint32_t)lane & 7u), py = ty * 8u + ((uint32_t)lane >> 3);
+            if (px >= c->W || py >= c->H) continue;
+            if (j->pass == 0) restir_generate_pixel(&tl, j, px, py); else if (j->pass == 2) restir_spatial_pixel(&tl, j, px, py); else restir_shade_pixel(&tl, j, px, py);
+        }
+    }
+    j->ctr = tl.ctr;
+    return NULL;
+}
+static void restir_pass(orc_ctx* c, const orc_restir_params_t* r, int pass, uint8_t* res_a, const uint8_t* res_read, int threads) {
+    if (threads < 1) threads = 1; if (threads > 256) threads = 256;
+    rjob_t jobs[256]; pthread_t th[256];
+    for (int i = 0; i < threads; i++) { jobs[i].c = c; jobs[i].r = r; jobs[i].pass = pass; jobs[i].tid = i; jobs[i].nthreads = threads; jobs[i].res_a = res_a; jobs[i].res_read = res_read; memset(&jobs[i].ctr, 0, sizeof(orc_counters_t)); }
+    if (threads == 1) restir_worker(&jobs[0]);
+    else { for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, restir_worker, &jobs[i]); for (int i = 0; i < threads; i++) pthread_join(th[i], NULL); }
+    for (int i = 0; i < threads; i++) acc_ctr(&c->ctr, &jobs[i].ctr);
+}
+/* RendererRESTIR::process, renderer_restir.cpp:129-251 */
+int orc_restir_process(orc_ctx* c, const orc_restir_params_t* r, const orc_uniform_t* u, int render, int threads) {
+    if (!c->rs_out) return -1;
+    c->u = *u;
+    const size_t px = (size_t)c->W * c->H;
+    if (!render) { memset(c->rs_out, 0, px * 64); memset(c->rs_irr, 0, px * 16); memset(c->rs_mom, 0, px * 8); } /* restir_di_clear.comp */
+    else {
+        const int spatial = r->spatial_reuse_iterations > 0;
+        uint8_t* a = spatial ? c->rs_pong : c->rs_out; /* the ping-pong of renderer_restir.cpp:136-146,213-250 */
+        restir_pass(c, r, 0, a, NULL, threads);
+        if (r->temporal_reuse_enable && c->rs_iteration > 0) restir_pass(c, r, 1, a, NULL, threads);
+        if (spatial) restir_pass(c, r, 2, c->rs_out, c->rs_pong, threads);
+        restir_pass(c, r, 3, c->rs_out, NULL, threads);
+    }
+    memcpy(c->rs_prev, c->rs_out, px * 64); memcpy(c->rs_prev_gb, c->gbuffer, px * sizeof(gbuf_t)); /* the graph's delay-1 inputs */
+    c->rs_iteration++;
+    return 0;
+}
+const void* orc_restir_output(orc_ctx* c, int which, size_t* bytes) {
+    size_t px = (size_t)c->W * c->H;
+    if (which == 0) { if (bytes) *bytes = px * 16; return c->rs_irr; }
+    if (which == 1) { if (bytes) *bytes = px * 8; return c->rs_mom; }
+    if (which == 2) { if (bytes) *bytes = px * 64; return c->rs_out; }
+    return NULL;
 }
 
 /* ---------------------------------------------------------------- post chain (definitions: DESIGN.md section 3) */

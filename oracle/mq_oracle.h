@@ -181,6 +181,21 @@ int orc_post_process(orc_ctx* c); /* after orc_process of the same frame */
 void orc_post_clear(orc_ctx* c);
 const void* orc_post_output(orc_ctx* c, int which, size_t* bytes);
 
+/* ---- ReSTIR DI node: src/render_restir/renderer_restir.cpp:129-251, res/shader/render_restir/{restir_di.glsl,
+ * restir_di_common.glsl, restir_di_generate_samples_bsdf.comp, restir_di_temporal_reuse.comp, restir_di_spatial_reuse.comp,
+ * restir_di_shade.comp, restir_di_clear.comp}.  Runs on the g-buffer outputs orc_process left for the same frame. */
+typedef struct {
+    int32_t spp; uint32_t seed; int32_t visibility_shade;
+    float temporal_normal_reject_cos, temporal_depth_reject, spatial_normal_reject_cos, spatial_depth_reject;
+    int32_t temporal_clamp_m, spatial_radius, temporal_bias_correction, spatial_bias_correction;
+    float boiling_filter_strength;
+    int32_t spatial_reuse_iterations; /* the property's value (0 = no spatial pass) */
+    int32_t apply_mv, temporal_reuse_enable;
+} orc_restir_params_t;
+int orc_restir_process(orc_ctx* c, const orc_restir_params_t* r, const orc_uniform_t* u, int render, int threads);
+/* which: 0 irradiance RGBA32F, 1 moments RG32F, 2 reservoirs (64 B per pixel) */
+const void* orc_restir_output(orc_ctx* c, int which, size_t* bytes);
+
 /* closest-hit queries (raytrace.glsl:82-119 semantics: back-face cull, alpha any-hit, tmin 0,
  * tmax 1e4).  out_prim = (slot << 28 | prim) or 0xffffffff on miss. */
 int orc_trace_rays(orc_ctx* c, const float* org, const float* dir, uint32_t n, uint32_t* out_prim,

@@ -36,6 +36,34 @@ class Params(C.Structure):
                 ("log_learning", C.c_int32)]
 
 
+class RestirParams(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("seed", C.c_uint32), ("visibility_shade", C.c_int32), ("temporal_normal_reject_cos", C.c_float),
+                ("temporal_depth_reject", C.c_float), ("spatial_normal_reject_cos", C.c_float), ("spatial_depth_reject", C.c_float),
+                ("temporal_clamp_m", C.c_int32), ("spatial_radius", C.c_int32), ("temporal_bias_correction", C.c_int32),
+                ("spatial_bias_correction", C.c_int32), ("boiling_filter_strength", C.c_float), ("spatial_reuse_iterations", C.c_int32),
+                ("apply_mv", C.c_int32), ("temporal_reuse_enable", C.c_int32)]
+
+
+RESERVOIR_DTYPE = np.dtype([("M", "<u4"), ("w", "<f4"), ("p_target", "<f4"), ("pos", "<f4", 3), ("normal", "<f4", 3), ("mv", "<f4", 3), ("T", "<f4"),
+                            ("rad", "<u2", 3), ("pad", "<u2"), ("flags", "<u4")])
+assert RESERVOIR_DTYPE.itemsize == 64
+
+
+def restir_params_from_ctx(ctx):
+    """the ReSTIR node's properties of a product context ("restir: ...") as the oracle's parameter block"""
+    import math
+    g = lambda k: ctx.get_property("restir: " + k)
+    r = RestirParams()
+    r.spp = int(g("spp")); r.seed = int(g("seed")); r.visibility_shade = int(g("shade visibility"))
+    r.temporal_normal_reject_cos = float(np.float32(math.cos(g("temporal normal threshold")))); r.temporal_depth_reject = g("temporal depth threshold")
+    r.spatial_normal_reject_cos = float(np.float32(math.cos(g("spatial normal threshold")))); r.spatial_depth_reject = g("spatial depth threshold")
+    r.temporal_clamp_m = int(g("temporal clamp m")); r.spatial_radius = int(g("spatital radius"))
+    r.temporal_bias_correction = int(g("temporal bias correction")); r.spatial_bias_correction = int(g("spatial bias correction"))
+    r.boiling_filter_strength = g("boiling filter strength"); r.spatial_reuse_iterations = int(g("spatial reuse iterations"))
+    r.apply_mv = int(g("apply mv")); r.temporal_reuse_enable = int(g("enable temporal reuse"))
+    return r
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "nodes", "tris", "segments", "guided_segments", "lc_touches",
                                           "mc_updates_accepted", "mc_updates_dropped", "mc_state_reads")]
@@ -69,6 +97,9 @@ def lib():
         l.orc_learn_log.argtypes = [P, C.POINTER(C.c_size_t)]
         l.orc_learn_log_reset.argtypes = [P, C.c_size_t]
         l.orc_debug_apply_updates.argtypes = [P, P, C.c_size_t, P, P, C.c_size_t, C.POINTER(C.c_size_t)]
+        l.orc_restir_process.argtypes = [P, C.POINTER(RestirParams), P, C.c_int, C.c_int]
+        l.orc_restir_output.restype = C.c_void_p
+        l.orc_restir_output.argtypes = [P, C.c_int, C.POINTER(C.c_size_t)]
         l.orc_post_set_params.argtypes = [P, C.c_int, P]
         l.orc_post_process.argtypes = [P]
         l.orc_post_clear.argtypes = [P]
@@ -197,6 +228,18 @@ class Oracle:
         p = self.l.orc_post_output(self.h, which, C.byref(n))
         a = np.frombuffer((C.c_char * n.value).from_address(p), dtype=np.float32).copy()
         return a.reshape(self.H, self.W, 4) if which in (0, 2, 4) else a.reshape(self.H, self.W)
+
+    def restir_process(self, rparams, uniform, render=True, threads=1):
+        assert self.l.orc_restir_process(self.h, C.byref(rparams), C.addressof(uniform), 1 if render else 0, threads) == 0
+
+    def restir_output(self, which):
+        """0 irradiance (H, W, 4) f32, 1 moments (H, W, 2) f32, 2 reservoirs (H * W) records"""
+        n = C.c_size_t()
+        p = self.l.orc_restir_output(self.h, which, C.byref(n))
+        raw = np.frombuffer((C.c_char * n.value).from_address(p), dtype=np.uint8).copy()
+        if which == 2:
+            return raw.view(RESERVOIR_DTYPE)
+        return raw.view(np.float32).reshape(self.H, self.W, 4 if which == 0 else 2)
 
     def learn_log_reset(self, capacity):
         assert self.l.orc_learn_log_reset(self.h, capacity) == 0

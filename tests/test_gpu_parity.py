@@ -308,16 +308,19 @@ def test_per_frame_geometry_update_parity(gpu_ctx):
     ctx.set_geometry(5, np.zeros((0, 3), np.float32), None, np.zeros((0, 3), np.uint32), np.zeros(0, mqhip.EXT_DTYPE), 0)
 
 
-@pytest.mark.parametrize("scene,seed,W,H", [("synth_sepulcher", 2, 1920, 1080),   # BASELINE config 3: 640 k triangles
-                                            ("synth_azad", 4, 3840, 2160)])       # config 5's size: 1.4 M triangles, 4K
-def test_full_size_frame_parity(gpu_ctx, scene, seed, W, H):
+@pytest.mark.parametrize("scene,seed,W,H,packets", [("synth_sepulcher", 2, 1920, 1080, 0),   # BASELINE config 3: 640 k triangles
+                                                    ("synth_sepulcher", 2, 1920, 1080, 1),   # the same with the camera rays walked as frustum packets
+                                                    ("synth_materials", 5, 1918, 1079, 1),   # alpha-tested triangles, partial tiles on both edges
+                                                    ("synth_azad", 4, 3840, 2160, 0)])       # config 5's size: 1.4 M triangles, 4K
+def test_full_size_frame_parity(gpu_ctx, scene, seed, W, H, packets):
     """The BASELINE configurations at their full sizes: one unguided frame, every pixel of the radiance image and of
     the first-hit records bit-identical to the oracle (which needs a few seconds on the host cores for it)."""
     import mqhip
     ctx = gpu_ctx
-    o = make_pair(ctx, scene, seed, {"reference mode": 1, "spp": 1, "max path length": 3}, W, H)
+    o = make_pair(ctx, scene, seed, {"reference mode": 1, "spp": 1, "max path length": 3, "camera rays: frustum packets": packets}, W, H)
     u = ctx.synth_camera(40)
     ctx.process(u)
+    ctx.set_property("camera rays: frustum packets", 0)
     o.process(u, threads=os.cpu_count() or 8)
     img, ref = ctx.irradiance(), o.irradiance()
     bad = (img.view(np.uint32) != ref.view(np.uint32)).any(-1)
