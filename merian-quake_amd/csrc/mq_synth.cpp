@@ -92,11 +92,12 @@ struct Gen {
         int nu = std::max(1, (int)std::ceil(lu / q - 1e-4f)), nv = std::max(1, (int)std::ceil(lv / q - 1e-4f));
         V du = eu * (1.0f / lu), dv = ev * (1.0f / lv);
         float s0 = dot(o - st_origin, du) / 64.0f, t0 = dot(o - st_origin, dv) / 64.0f;
+        const int lone = light_frac < 0.0f ? rng.range(nu * nv) : -1; // light_frac < 0: exactly one emissive tile on this face
         for (int j = 0; j < nv; j++) for (int i = 0; i < nu; i++) {
             float u0 = lu * i / nu, u1 = lu * (i + 1) / nu, v0 = lv * j / nv, v1 = lv * (j + 1) / nv;
             V a = o + du * u0 + dv * v0, b = o + du * u1 + dv * v0, c = o + du * u1 + dv * v1, d = o + du * u0 + dv * v1;
             float st[8] = {s0 + u0 / 64.0f, t0 + v0 / 64.0f, s0 + u1 / 64.0f, t0 + v0 / 64.0f, s0 + u1 / 64.0f, t0 + v1 / 64.0f, s0 + u0 / 64.0f, t0 + v1 / 64.0f};
-            bool em = light_frac > 0.0f && rng.uni() < light_frac;
+            bool em = lone >= 0 ? (j * nu + i == lone) : (light_frac > 0.0f && rng.uni() < light_frac);
             mq_ext e = material(tex, em, fancy);
             if (flags_override >= 0) e.texnum_fb_flags = (uint16_t)((e.texnum_fb_flags & 0xfffu) | ((uint32_t)flags_override << 12));
             m.quad(a, b, c, d, n, st, e);
@@ -202,10 +203,12 @@ void make_textures(mq_ctx* ctx, Rng& rng) {
 
 bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string& err) {
     int G; float q; float outdoor_frac; float sun_k; float mu_t = 0.0f;
+    bool lamps = false;
     bool material_zoo = false; // panels of every material class of raytrace.glsl:95-119,198-204,246-311 in every room
     if (!strcmp(name, "synth_materials")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; mu_t = 1e-3f; material_zoo = true; }
     else if (!strcmp(name, "synth_start")) { G = 4; q = 32.0f; outdoor_frac = 0.0f; sun_k = 0.0f; }
     else if (!strcmp(name, "synth_tiny")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; }
+    else if (!strcmp(name, "synth_lamps")) { G = 3; q = 48.0f; outdoor_frac = 0.0f; sun_k = 0.0f; lamps = true; } // indoor, ONE small ceiling light per room: the lighting guiding is made for
     else if (!strcmp(name, "synth_tiny_fog")) { G = 2; q = 128.0f; outdoor_frac = 0.25f; sun_k = 3.0f; mu_t = 2e-3f; }
     else if (!strcmp(name, "synth_start_fog")) { G = 4; q = 32.0f; outdoor_frac = 0.2f; sun_k = 4.0f; mu_t = 2e-3f; }
     else if (!strcmp(name, "synth_sepulcher")) { G = 8; q = 16.0f; outdoor_frac = 0.4f; sun_k = 4.0f; }
@@ -220,6 +223,7 @@ bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string
     gen.world.g->flags = MQ_GEO_OPAQUE | MQ_GEO_STATIC; // selector 1, quake_node.cpp:863-871
     gen.alpha.g->flags = MQ_GEO_STATIC;                  // selector 2 (alpha tested), quake_node.cpp:884-892
     gen.dyn.g->flags = MQ_GEO_OPAQUE;                    // per-frame geometry, quake_node.cpp:896-983
+    if (lamps) { gen.light_frac_ceiling = -1.0f; gen.light_frac_wall = 0.0f; }
     Rng& rng = gen.rng;
     make_textures(ctx, rng);
 
