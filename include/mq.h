@@ -296,6 +296,38 @@ int mq_synth_camera(const mq_ctx* ctx, uint32_t frame, mq_uniform* out);
 /* Quake BSP29 / BSP2 world model + palette (768-byte file or NULL for a built-in grey ramp) */
 int mq_load_bsp(mq_ctx* ctx, const char* bsp_path, const char* palette_path);
 
+/* ---- per-frame geometry producers: QuakeNode::update_dynamic_geo, src/game/quake_node.cpp:896-983 ----
+ * The reference collects, every frame, the view model, the visible and static entities and the particles into ONE
+ * non-opaque geometry (add_geo / add_particles, src/game/quake_helpers.cpp:50-652) from quakespasm's live structures.
+ * Here the same quantities come in through plain structs; models are read from id Software's own file formats.
+ *     mq_dyn_begin(ctx); mq_dyn_add_*(...) ...; mq_dyn_end(ctx, slot); mq_scene_commit(ctx);   -- once per frame */
+typedef struct mq_view { float origin[3], forward[3], right[3], up[3]; } mq_view; /* r_refdef.vieworg, AngleVectors(r_refdef.viewangles) */
+enum { MQ_PT_FIRE = 3, MQ_PT_EXPLODE2 = 5 }; /* quakespasm ptype_t values the heuristics of quake_helpers.cpp:95-113 look at */
+typedef struct mq_particle { /* particle_t: org, the fork's mv_prev_origin, vel, d_8to24table[color], type; seed = the fork's per-particle RNG seed (p->die with "reproducible renders", quake_helpers.cpp:82-84) */
+    float org[3], prev_org[3], vel[3];
+    uint32_t color_rgba;
+    int32_t type;
+    uint32_t seed;
+} mq_particle;
+typedef struct mq_alias_instance { /* what add_geo_alias takes from entity_t / lerpdata_t, quake_helpers.cpp:244-303 */
+    float origin[3], angles[3];           /* lerpdata.origin / lerpdata.angles (pitch, yaw, roll in degrees, as R_SetupEntityTransform leaves them) */
+    float prev_origin[3], prev_angles[3]; /* the same one frame ago (the fork's mv_prev_origin / mv_prev_angles before their sign flip) */
+    int32_t pose1, pose2; float blend, prev_blend; /* lerpdata.pose1 / pose2 / blend, ent->mv_prev_blend */
+    int32_t skin;                         /* ent->skinnum */
+    float fovscale;                       /* view model only: tan(fov / 2) if fov > 90 (quake_helpers.cpp:244-246), else 0 or 1 */
+} mq_alias_instance;
+typedef struct mq_sprite_instance { float origin[3], prev_origin[3], angles[3]; float scale; int32_t frame; } mq_sprite_instance;
+int mq_dyn_begin(mq_ctx* ctx);
+int mq_dyn_add_particles(mq_ctx* ctx, const mq_particle* particles, uint32_t n, const mq_view* view, uint32_t texnum_blood, uint32_t texnum_explosion, double cl_time, double prev_cl_time); /* add_particles, quake_helpers.cpp:50-216 */
+int mq_dyn_add_alias(mq_ctx* ctx, int alias_model, const mq_alias_instance* inst);                                   /* add_geo_alias, :218-359 */
+int mq_dyn_add_sprite(mq_ctx* ctx, int sprite_model, const mq_sprite_instance* inst, const mq_view* view);           /* add_geo_sprite, :471-626 */
+int mq_dyn_add_brush_model(mq_ctx* ctx, int bsp_model, const float origin[3], const float angles[3], const float prev_origin[3], const float prev_angles[3]); /* add_geo_brush for an entity, :362-469 */
+int mq_dyn_end(mq_ctx* ctx, int slot); /* -> mq_scene_set_geometry(slot, ..., flags 0): alpha tests apply, rebuilt every frame (quake_node.cpp:969-981) */
+int mq_bsp_model_count(const mq_ctx* ctx); /* brush models of the BSP loaded by mq_load_bsp (model 0 = the world, already in slots 0 / 1) */
+/* MDL ("IDPO" version 6) / SPR ("IDSP" version 1) files; their pictures become textures first_texnum.. (next free number in *next_texnum) */
+int mq_load_mdl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* alias_model, uint32_t* next_texnum);
+int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* sprite_model, uint32_t* next_texnum);
+
 #ifdef __cplusplus
 }
 #endif

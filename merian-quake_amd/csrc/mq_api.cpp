@@ -61,6 +61,7 @@ struct mq_ctx {
     MqHostGeo geo[MQ_MAX_GEOMETRIES];
     std::vector<MqHostTex> tex;
     MqSynthInfo synth;
+    MqProducerState producers;
     // committed scene (host copies kept for stats / debugging)
     std::vector<MqNode> nodes;
     std::vector<MqTri> tris;
@@ -149,10 +150,13 @@ MqHostGeo& mq_ctx_geo(mq_ctx* c, int slot) { c->static_dirty = true; return c->g
 MqHostTex& mq_ctx_tex(mq_ctx* c, uint32_t t) { c->tex_dirty = true; return c->tex[t]; }
 mq_constants& mq_ctx_constants(mq_ctx* c) { return c->constants; }
 MqSynthInfo& mq_ctx_synth(mq_ctx* c) { return c->synth; }
+MqProducerState& mq_ctx_producers(mq_ctx* c) { return c->producers; }
+int mq_ctx_fail(mq_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 void mq_ctx_clear_scene(mq_ctx* c) {
     for (auto& g : c->geo) g = MqHostGeo();
     for (auto& t : c->tex) t = MqHostTex();
     c->synth = MqSynthInfo();
+    c->producers = MqProducerState();
     c->committed = false; c->static_dirty = c->tex_dirty = true;
 }
 

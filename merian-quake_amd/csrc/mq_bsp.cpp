@@ -6,8 +6,11 @@
 //   texture upload (sRGB RGBA8, fullbright mask)      src/game/quake_node.cpp:683-704
 //   worldspawn sun keys                               src/game/quake_node.cpp:231-313
 // The on-disk layouts are id Software's BSP29 and the BSP2 extension (32-bit face/edge indices).
-// Only the world model (model 0) is read; entities' brush models, alias models, sprites and
-// particles are dynamic geometry that the game would hand over per frame.
+// Model 0 (the world) becomes the static geometry; the other brush models (doors, platforms, ...) are kept in model
+// space for mq_dyn_add_brush_model (mq_producers.cpp), which places them per frame as add_geo_brush does for an entity.
+// External normal / gloss maps (`<texture>_norm.tga`, `<texture>_gloss.tga` in a textures/ directory beside or above the
+// map, as the reference's quakespasm fork loads them: t->norm / t->gloss, quake_helpers.cpp:428-431) are uploaded
+// linear (quake_node.hpp:93-95) and referenced from VertexExtraData::n0_gloss_norm.
 #include "mq_host.h"
 
 #include <cmath>
@@ -46,6 +49,30 @@ uint16_t f2h_host(float f) {
     uint32_t hm = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
     if (rem > half || (rem == half && (hm & 1u))) hm++;
     return (uint16_t)(sign | (hexp == 0 ? hm : ((hexp - 1) << 10) + hm));
+}
+
+// uncompressed / RLE true-colour TGA (types 2, 10; 24 or 32 bits) -> RGBA8, top row first
+bool read_tga(const char* path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
+    std::vector<uint8_t> f;
+    if (!read_file(path, f) || f.size() < 18) return false;
+    const uint8_t idlen = f[0], cmap = f[1], type = f[2], bpp = f[16], desc = f[17];
+    w = f[12] | (f[13] << 8); h = f[14] | (f[15] << 8);
+    if (cmap || (type != 2 && type != 10) || (bpp != 24 && bpp != 32) || !w || !h || w > 8192 || h > 8192) return false;
+    const size_t bytes = bpp / 8, n = (size_t)w * h;
+    size_t at = 18 + idlen;
+    std::vector<uint8_t> px(n * 4);
+    auto put = [&](size_t i, const uint8_t* p) { px[4 * i] = p[2]; px[4 * i + 1] = p[1]; px[4 * i + 2] = p[0]; px[4 * i + 3] = bytes == 4 ? p[3] : 255; };
+    if (type == 2) { if (at + n * bytes > f.size()) return false; for (size_t i = 0; i < n; i++) put(i, &f[at + i * bytes]); }
+    else for (size_t i = 0; i < n;) {
+        if (at >= f.size()) return false;
+        const uint8_t c = f[at++]; const size_t run = (size_t)(c & 0x7f) + 1;
+        if (c & 0x80) { if (at + bytes > f.size()) return false; for (size_t k = 0; k < run && i < n; k++) put(i++, &f[at]); at += bytes; }
+        else { if (at + run * bytes > f.size()) return false; for (size_t k = 0; k < run && i < n; k++) put(i++, &f[at + k * bytes]); at += run * bytes; }
+    }
+    rgba.resize(n * 4);
+    const bool top_first = (desc & 0x20) != 0;
+    for (uint32_t y = 0; y < h; y++) memcpy(&rgba[4 * (size_t)y * w], &px[4 * (size_t)(top_first ? y : h - 1 - y) * w], 4 * (size_t)w);
+    return true;
 }
 
 // first { ... } block of the entity lump -> key/value map (COM_Parse semantics, quake_node.cpp:241-264)
@@ -101,7 +128,20 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
 
     mq_ctx_clear_scene(ctx);
     // ---- textures (lump 2) ---------------------------------------------------------------------
-    struct TexMeta { std::string name; uint32_t w = 0, h = 0; uint32_t texnum = 0, fb = 0; bool alpha = false, sky = false, turb = false; int turb_flag = 0; };
+    struct TexMeta { std::string name; uint32_t w = 0, h = 0; uint32_t texnum = 0, fb = 0, norm = 0, gloss = 0; bool alpha = false, sky = false, turb = false; int turb_flag = 0; };
+    std::string dir = bsp_path; { size_t sl = dir.find_last_of('/'); dir = sl == std::string::npos ? std::string(".") : dir.substr(0, sl); }
+    uint32_t next_tex = 1;
+    auto external = [&](const std::string& name, const char* suffix) -> uint32_t { // <name><suffix>.tga under textures/ beside or above the map; '*' of liquid names is '#' on disk
+        std::string base = name; for (char& ch : base) if (ch == '*') ch = '#';
+        for (const char* sub : {"/textures/", "/../textures/"}) {
+            uint32_t w = 0, h = 0; std::vector<uint8_t> px;
+            if (!read_tga((dir + sub + base + suffix + ".tga").c_str(), w, h, px) || next_tex + 1 >= MQ_MAX_GLTEXTURES) continue;
+            const uint32_t tn = next_tex++;
+            MqHostTex& t = mq_ctx_tex(ctx, tn); t.w = w; t.h = h; t.flags = MQ_TEX_LINEAR | MQ_TEX_MIPMAP; t.px = px; // not sRGB: quake_node.hpp:93-95
+            return tn;
+        }
+        return 0u;
+    };
     std::vector<TexMeta> metas;
     uint32_t sky_back = 0xffffu, sky_front = 0xffffu;
     if (lumps[2].len >= 4) {
@@ -109,7 +149,6 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
         int32_t nmip; memcpy(&nmip, base, 4);
         if (nmip < 0 || (size_t)nmip * 4 + 4 > (size_t)lumps[2].len) { err = "bad miptex directory"; return false; }
         metas.resize((size_t)nmip);
-        uint32_t next_tex = 1;
         for (int i = 0; i < nmip; i++) {
             int32_t ofs; memcpy(&ofs, base + 4 + 4 * i, 4);
             TexMeta& m = metas[(size_t)i];
@@ -156,6 +195,7 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
                 d[3] = (m.alpha && ci == 255) ? 0 : 255;
                 if (ci >= 224 && !(m.alpha && ci == 255)) any_fb = true;
             }
+            if (!m.turb && !m.sky) { m.norm = external(m.name, "_norm"); m.gloss = external(m.name, "_gloss"); }
             if (any_fb && src && !m.turb) { // fullbright mask texture: non-fullbright texels are black
                 m.fb = next_tex++;
                 MqHostTex& f = mq_ctx_tex(ctx, m.fb); f.w = m.w; f.h = m.h; f.flags = MQ_TEX_SRGB | MQ_TEX_MIPMAP; f.px.assign(px * 4, 0);
@@ -185,16 +225,16 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
         if (bsp2) { memcpy(&v0, p, 4); memcpy(&v1, p + 4, 4); } else { uint16_t a, b; memcpy(&a, p, 2); memcpy(&b, p + 2, 2); v0 = a; v1 = b; }
         return lindex >= 0 ? v0 : v1;
     };
-    for (int32_t fi = 0; fi < world.numfaces; fi++) {
-        const uint8_t* fp = lump_ptr(7) + (size_t)(world.firstface + fi) * face_sz;
+    auto emit_face = [&](int32_t face, MqHostGeo& opaque, MqHostGeo& alpha) {
+        const uint8_t* fp = lump_ptr(7) + (size_t)face * face_sz;
         int32_t firstedge, numedges, ti;
         if (bsp2) { memcpy(&firstedge, fp + 8, 4); memcpy(&numedges, fp + 12, 4); memcpy(&ti, fp + 16, 4); }
         else { int16_t ne, t16; memcpy(&firstedge, fp + 4, 4); memcpy(&ne, fp + 8, 2); memcpy(&t16, fp + 10, 2); numedges = ne; ti = t16; }
-        if (numedges < 3 || firstedge < 0 || (size_t)firstedge + (size_t)numedges > nsurfedges || ti < 0 || (size_t)ti >= ntexinfo) continue;
+        if (numedges < 3 || firstedge < 0 || (size_t)firstedge + (size_t)numedges > nsurfedges || ti < 0 || (size_t)ti >= ntexinfo) return;
         const TexInfo& tx = texinfo[ti];
-        if (tx.miptex < 0 || (size_t)tx.miptex >= metas.size()) continue;
+        if (tx.miptex < 0 || (size_t)tx.miptex >= metas.size()) return;
         const TexMeta& m = metas[(size_t)tx.miptex];
-        if (!strcasecmp(m.name.c_str(), "skip")) continue; // quake_helpers.cpp:391
+        if (!strcasecmp(m.name.c_str(), "skip")) return; // quake_helpers.cpp:391
         MqHostGeo& g = m.alpha ? alpha : opaque;
         uint32_t base = (uint32_t)(g.vtx.size() / 3);
         std::vector<float> st((size_t)numedges * 2);
@@ -208,11 +248,12 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
             float t = v[0] * tx.vecs[1][0] + v[1] * tx.vecs[1][1] + v[2] * tx.vecs[1][2] + tx.vecs[1][3];
             st[2 * k] = m.w ? s / (float)m.w : 0.0f; st[2 * k + 1] = m.h ? t / (float)m.h : 0.0f;
         }
-        if (!ok) { g.vtx.resize(3 * (size_t)base); g.prev_vtx.resize(3 * (size_t)base); continue; }
+        if (!ok) { g.vtx.resize(3 * (size_t)base); g.prev_vtx.resize(3 * (size_t)base); return; }
         for (int32_t k = 2; k < numedges; k++) { // fan, quake_helpers.cpp:419-423
             g.idx.push_back(base); g.idx.push_back(base + (uint32_t)k - 1); g.idx.push_back(base + (uint32_t)k);
             mq_ext e; memset(&e, 0, sizeof e);
             e.n1_brush = 0xffffffffu;
+            e.n0_gloss_norm = (m.gloss & 0xffffu) | (m.norm << 16); // pack_uint32(gloss, norm), quake_helpers.cpp:428-431
             e.st[0] = f2h_host(st[0]); e.st[1] = f2h_host(st[1]);
             e.st[2] = f2h_host(st[2 * (k - 1)]); e.st[3] = f2h_host(st[2 * (k - 1) + 1]);
             e.st[4] = f2h_host(st[2 * k]); e.st[5] = f2h_host(st[2 * k + 1]);
@@ -226,6 +267,17 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
             if (m.sky) flags = MQ_MAT_FLAGS_SKY;
             e.texnum_fb_flags = (uint16_t)((e.texnum_fb_flags & 0xfffu) | (flags << 12));
             g.ext.push_back(e);
+        }
+    };
+    for (int32_t fi = 0; fi < world.numfaces; fi++) emit_face(world.firstface + fi, opaque, alpha);
+    { // the other brush models, in model space, for the per-frame producer
+        MqProducerState& P = mq_ctx_producers(ctx);
+        const size_t nmodels = (size_t)lumps[14].len / sizeof(Model);
+        P.bsp_models.assign(nmodels, MqHostGeo());
+        for (size_t mi = 1; mi < nmodels; mi++) {
+            Model sub; memcpy(&sub, lump_ptr(14) + mi * sizeof(Model), sizeof sub);
+            if (sub.firstface < 0 || sub.numfaces < 0 || (size_t)sub.firstface + (size_t)sub.numfaces > nfaces) continue;
+            for (int32_t fi = 0; fi < sub.numfaces; fi++) emit_face(sub.firstface + fi, P.bsp_models[mi], P.bsp_models[mi]);
         }
     }
     // ---- worldspawn + player start ---------------------------------------------------------------

@@ -100,6 +100,29 @@ struct mq_ctx;
 bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string& err);
 bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, std::string& err);
 
+// Per-frame geometry producers (mq_producers.cpp) and what the loaders keep for them
+struct MqAliasModel { // an MDL file as quakespasm's GL_MakeAliasModelDisplayLists_VBO lays it out
+    float scale[3], scale_origin[3];
+    uint32_t skinwidth = 0, skinheight = 0, numverts = 0, numposes = 0;
+    std::vector<uint8_t> trivertexes;   // numposes * numverts * 4 bytes: v[3], lightnormalindex
+    std::vector<uint16_t> vertindex;    // per VBO vertex: index into a pose's vertices
+    std::vector<float> st;              // per VBO vertex: s, t in texels
+    std::vector<uint16_t> indexes;      // 3 per triangle, into the VBO vertices
+    std::vector<uint32_t> skin_texnum, skin_fb_texnum, skin_norm_texnum, skin_gloss_texnum; // per skin
+};
+struct MqSpriteFrame { float up, down, left, right, smax, tmax; uint32_t texnum; bool alpha; };
+struct MqSpriteModel { int32_t type = 0; std::vector<MqSpriteFrame> frames; };
+struct MqProducerState {
+    std::vector<MqHostGeo> bsp_models; // brush models 1.. of the loaded BSP, in model space (index 0 unused: the world)
+    std::vector<MqAliasModel> alias;
+    std::vector<MqSpriteModel> sprites;
+    MqHostGeo pending;                 // the per-frame geometry being collected (mq_dyn_begin .. mq_dyn_end)
+    bool collecting = false;
+};
+MqProducerState& mq_ctx_producers(mq_ctx* ctx);
+int mq_ctx_fail(mq_ctx* ctx, int code, const std::string& msg);
+bool mq_read_palette(const char* palette_path, uint8_t pal[768], std::string& err); // 768-byte palette.lmp, or the grey ramp for NULL
+
 // host-side access used by the generators / loaders
 MqHostGeo& mq_ctx_geo(mq_ctx* ctx, int slot);
 MqHostTex& mq_ctx_tex(mq_ctx* ctx, uint32_t texnum);

@@ -61,6 +61,22 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class View(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("forward", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3)]
+
+
+PARTICLE_DTYPE = np.dtype([("org", "<f4", 3), ("prev_org", "<f4", 3), ("vel", "<f4", 3), ("color_rgba", "<u4"), ("type", "<i4"), ("seed", "<u4")])
+
+
+class AliasInstance(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("angles", C.c_float * 3), ("prev_origin", C.c_float * 3), ("prev_angles", C.c_float * 3),
+                ("pose1", C.c_int32), ("pose2", C.c_int32), ("blend", C.c_float), ("prev_blend", C.c_float), ("skin", C.c_int32), ("fovscale", C.c_float)]
+
+
+class SpriteInstance(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("prev_origin", C.c_float * 3), ("angles", C.c_float * 3), ("scale", C.c_float), ("frame", C.c_int32)]
+
+
 class MqError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("mq error %d: %s" % (code, msg))
@@ -125,6 +141,15 @@ def load_library(path=None):
         "mq_debug_state_read": (i32, [P, i32, vp, sz]),
         "mq_debug_state_write": (i32, [P, i32, vp, sz]),
         "mq_debug_section_clocks": (i32, [P, C.POINTER(C.c_uint64), i32, i32]),
+        "mq_dyn_begin": (i32, [P]),
+        "mq_dyn_add_particles": (i32, [P, vp, u32, C.POINTER(View), u32, u32, C.c_double, C.c_double]),
+        "mq_dyn_add_alias": (i32, [P, i32, C.POINTER(AliasInstance)]),
+        "mq_dyn_add_sprite": (i32, [P, i32, C.POINTER(SpriteInstance), C.POINTER(View)]),
+        "mq_dyn_add_brush_model": (i32, [P, i32, f32p, f32p, f32p, f32p]),
+        "mq_dyn_end": (i32, [P, i32]),
+        "mq_bsp_model_count": (i32, [P]),
+        "mq_load_mdl": (i32, [P, C.c_char_p, C.c_char_p, u32, C.POINTER(i32), u32p]),
+        "mq_load_spr": (i32, [P, C.c_char_p, C.c_char_p, u32, C.POINTER(i32), u32p]),
         "mq_post_process": (i32, [P, vp]),
         "mq_restir_process": (i32, [P, C.POINTER(Uniform), i32, vp]),
         "mq_post_clear": (i32, [P]),
@@ -375,6 +400,40 @@ class Context:
     def state_write(self, which, a):
         a = np.ascontiguousarray(a, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE)[which])
         self._chk(self.lib.mq_debug_state_write(self.h, which, a.ctypes.data, a.nbytes))
+
+    # -- per-frame geometry producers (QuakeNode::update_dynamic_geo)
+    def dyn_begin(self):
+        self._chk(self.lib.mq_dyn_begin(self.h))
+
+    def dyn_end(self, slot):
+        self._chk(self.lib.mq_dyn_end(self.h, slot))
+
+    def dyn_add_particles(self, particles, view, texnum_blood, texnum_explosion, cl_time, prev_cl_time):
+        p = np.ascontiguousarray(particles, PARTICLE_DTYPE)
+        self._chk(self.lib.mq_dyn_add_particles(self.h, p.ctypes.data, len(p), C.byref(view), texnum_blood, texnum_explosion, cl_time, prev_cl_time))
+
+    def dyn_add_alias(self, model, inst):
+        self._chk(self.lib.mq_dyn_add_alias(self.h, model, C.byref(inst)))
+
+    def dyn_add_sprite(self, model, inst, view):
+        self._chk(self.lib.mq_dyn_add_sprite(self.h, model, C.byref(inst), C.byref(view)))
+
+    def dyn_add_brush_model(self, model, origin, angles, prev_origin, prev_angles):
+        f3 = lambda v: (C.c_float * 3)(*v)
+        self._chk(self.lib.mq_dyn_add_brush_model(self.h, model, f3(origin), f3(angles), f3(prev_origin), f3(prev_angles)))
+
+    def bsp_model_count(self):
+        return self.lib.mq_bsp_model_count(self.h)
+
+    def load_mdl(self, path, first_texnum, palette=None):
+        m, nt = C.c_int(), C.c_uint32()
+        self._chk(self.lib.mq_load_mdl(self.h, path.encode(), palette.encode() if palette else None, first_texnum, C.byref(m), C.byref(nt)))
+        return m.value, nt.value
+
+    def load_spr(self, path, first_texnum, palette=None):
+        m, nt = C.c_int(), C.c_uint32()
+        self._chk(self.lib.mq_load_spr(self.h, path.encode(), palette.encode() if palette else None, first_texnum, C.byref(m), C.byref(nt)))
+        return m.value, nt.value
 
     def restir_process(self, uniform, render=True, stream=None):
         self._chk(self.lib.mq_restir_process(self.h, C.byref(uniform), 1 if render else 0, stream))
