@@ -219,7 +219,10 @@ int mq_reset_state(mq_ctx* ctx); /* next process() behaves like iteration 0 */
  * all zero in a product build.  Section ids: tools/prof_sections.py. */
 /* Learning state in the device layout: which 0 = Markov-chain table (64 B per state: w_tgt f32x3, sum_w, w_cos, T, id u32,
  * N | hash << 16 u32, mv f16x3, padding), 1 = light cache (16 B per cell: hash u32, lock u32, irradiance f16x3, N u16),
- * 2 = distance Markov chains (16 B: sum_w f32, N u32, m0 f32, m1 f32).
+ * 2 = distance Markov chains (16 B: sum_w f32, N u32, m0 f32, m1 f32); read only, kept while the property "debug: LC lock
+ * statistics" is set (the reference's dump statistics, render_mcpg.cpp:354-416): 3 = per light-cache cell update_succeeded,
+ * update_canceled (2 x u32, grid.h:44-45; the light cache then runs the reference's try-lock, light_cache.glsl:59-64),
+ * 4 = per Markov-chain slot last_update_count (u32, grid.h:25).
  * `bytes` must equal the table size.  Writing needs one processed frame (the first frame zeroes the tables).
  * Test hook, with the property "debug: freeze learning": a guided frame from a given state is deterministic. */
 int mq_debug_state_read(mq_ctx* ctx, int which, void* dst_host, size_t bytes);

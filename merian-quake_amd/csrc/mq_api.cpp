@@ -96,6 +96,7 @@ struct mq_ctx {
     uint64_t restir_iteration = 0; bool restir_seeded = false; uint32_t restir_seed_in_use = 0;
     DevBuf d_post_prev_gb, d_post_prev_out[2], d_post_prev_hist[2]; // post chain: last frame's g-buffer, accumulated images and histories (surface, volume)
     bool post_first = true;
+    DevBuf d_lc_stats, d_last_upd; // "debug: LC lock statistics": allocated by the first frame that keeps them
     DevBuf d_learn_log, d_learn_count; // "debug: log learning writes": allocated by the first frame that logs
     uint32_t learn_log_cap = 0;
     uint32_t dist_mc_n = 0;
@@ -268,6 +269,7 @@ const PropDesc k_props[] = {
     {"restir: shade visibility", PT_BOOL, POFF(restir_shade_visibility), false, {}},
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
+    {"debug: LC lock statistics", PT_BOOL, POFF(lc_lock_statistics), false, {}},
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
@@ -379,7 +381,7 @@ void props_to_params(mq_ctx* c) {
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
     P.volume_forward_project = q.volume_forward_project;
-    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning; P.log_learning = q.log_learning; P.debug_output_connected = q.debug_output_connected;
+    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning; P.log_learning = q.log_learning; P.lc_lock_protocol = q.lc_lock_statistics; P.debug_output_connected = q.debug_output_connected;
     P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
     for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
@@ -394,7 +396,7 @@ void free_frame_state(mq_ctx* c) {
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
     dev_free(c->d_restir_pong); dev_free(c->d_restir_prev); dev_free(c->d_restir_prev_gb);
     dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
-    dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0;
+    dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0; dev_free(c->d_lc_stats); dev_free(c->d_last_upd);
     dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); c->shaded_valid[0] = c->shaded_valid[1] = false;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
@@ -954,6 +956,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     F.ray_cap = sub < 0 ? c->ray_cap : c->sub_ray_cap;
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
     F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
+    F.lc_stats = (uint2*)c->d_lc_stats.p; F.last_upd_count = (uint32_t*)c->d_last_upd.p;
     F.learn_log = (uint4*)c->d_learn_log.p; F.learn_log_count = (uint32_t*)c->d_learn_count.p; F.learn_log_cap = c->learn_log_cap;
     const int K = c->params.reference_mode ? 0 : std::max(0, c->params.mc_samples);
     F.lds_rows2 = (uint32_t)std::max(mq_stack_lds_entries(), (6 * K + 1) / 2);
@@ -1022,6 +1025,10 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->params_dirty) props_to_params(c);
     { int r = ensure_queue(c); if (r) return r; }
+    if (c->params.lc_lock_protocol && !c->d_lc_stats.p) { // statistics start at zero when they are switched on
+        int r = dev_alloc(c, c->d_lc_stats, (size_t)c->lc_total * 8); if (!r) r = dev_alloc(c, c->d_last_upd, (size_t)c->mc_total * 4); if (r) return r;
+        HIPCHK(c, hipMemsetAsync(c->d_lc_stats.p, 0, c->d_lc_stats.bytes, s)); HIPCHK(c, hipMemsetAsync(c->d_last_upd.p, 0, c->d_last_upd.bytes, s));
+    }
     if (c->params.log_learning) { int r = ensure_learn_log(c); if (r) return r; HIPCHK(c, hipMemsetAsync(c->d_learn_count.p, 0, 16, s)); } // the log holds ONE frame
     MqFrame F; fill_frame(c, u, F);
     { int r = frame_grids(c, F); if (r) return r; }
@@ -1268,7 +1275,9 @@ int mq_debug_section_clocks(mq_ctx* c, uint64_t* out, int n, int reset) {
 static int state_buf(mq_ctx* c, int which, DevBuf** b) {
     if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
     if (which == 0) *b = &c->d_mc; else if (which == 1) *b = &c->d_lc; else if (which == 2) *b = &c->d_dist_mc;
-    else return fail(c, MQ_EINVAL, "state: 0 = Markov chains, 1 = light cache, 2 = distance Markov chains");
+    else if ((which == 3 || which == 4) && c->d_lc_stats.p) *b = which == 3 ? &c->d_lc_stats : &c->d_last_upd;
+    else if (which == 3 || which == 4) return fail(c, MQ_ESTATE, "no statistics: set \"debug: LC lock statistics\" and render a frame");
+    else return fail(c, MQ_EINVAL, "state: 0 = Markov chains, 1 = light cache, 2 = distance Markov chains, 3 = light-cache lock statistics, 4 = last update counts");
     return MQ_OK;
 }
 int mq_debug_state_read(mq_ctx* c, int which, void* dst, size_t bytes) {

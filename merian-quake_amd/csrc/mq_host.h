@@ -74,6 +74,7 @@ struct MqProps {
     bool debug_output_connected = false; // the reference derives this from the graph wiring (render_mcpg.cpp:182-183)
     bool freeze_learning = false; // test hook, not a reference property
     bool log_learning = false;    // test hook, not a reference property
+    bool lc_lock_statistics = false; // the reference's light-cache try-lock with per-cell counters + last_update_count per slot (for the state dumps)
     bool overlap_camera_rays = false; // scheduling of this build: the camera rays of frame n + 1 traced beside the kernels of frame n (measured: no gain)
     bool packet_camera_rays = false;  // scheduling of this build: camera rays as one frustum packet per 8x8 tile (bit-identical; measured slower than the per-lane walk)
     int pipelines = 1; // scheduling of this build, not a reference property: sub-pipelines per frame (mq_api.cpp mq_process)

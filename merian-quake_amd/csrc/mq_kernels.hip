@@ -681,8 +681,10 @@ MQ_DEV void light_cache_update(const MqParams& P, const MqFrame& F, uint32_t& rn
     const mq_uniform& U = F.u; MqLCCell* const lc = F.lc;
     uint32_t level = lc_level(P, U, pos), idx, chk;
     lc_address(P, rng, level, pos, normal, idx, chk);
-    if (U.frame == 0u) { ctr.lc_cancel++; return; }
+    if (U.frame == 0u) { ctr.lc_cancel++; if (P.lc_lock_protocol && F.lc_stats) atomicAdd(&F.lc_stats[idx].y, 1u); return; }
     MqLCCell* cell = lc + idx;
+    const bool locked = P.lc_lock_protocol && !P.freeze_learning && F.lc_stats; // statistics mode: the reference's try-lock, light_cache.glsl:59-64
+    if (locked && atomicExch(&cell->lock, U.frame) == U.frame) { atomicAdd(&F.lc_stats[idx].y, 1u); ctr.lc_cancel++; return; }
     uint4 c = *(const uint4*)cell;
     uint16_t i0 = (uint16_t)(c.z & 0xffffu), i1 = (uint16_t)(c.z >> 16), i2 = (uint16_t)(c.w & 0xffffu);
     f3 cur; uint32_t N;
@@ -702,8 +704,9 @@ MQ_DEV void light_cache_update(const MqParams& P, const MqFrame& F, uint32_t& rn
     // (irradiance, N) payload.  Two lanes racing on one cell lose one of the two updates -- the
     // reference drops contended updates too -- and scattered atomics (about 20 G/s on this chip)
     // would otherwise bound the kernel.
-    if (rekey) *(uint4*)cell = make_uint4(chk, 0u, nz, nw);
+    if (rekey) *(uint4*)cell = make_uint4(chk, locked ? U.frame : 0u, nz, nw);
     else *(uint2*)&cell->irr[0] = make_uint2(nz, nw);
+    if (locked) { atomicAdd(&F.lc_stats[idx].x, 1u); __threadfence(); cell->lock = 0u; } // :82-83
     ctr.lc_ok++;
 }
 
@@ -1941,6 +1944,7 @@ MQ_DEV uint32_t apply_slot(const MqParams& P, const MqFrame& F, uint32_t slot, u
           new_state.hash = h16; MCS old = mc_load(F.mc, bi);
           if (old.id == new_state.id || xorshift(rng) < new_state.sum_w / (new_state.sum_w + old.sum_w)) mc_store(F.mc, bi, new_state); }
     }
+    if (F.last_upd_count) F.last_upd_count[slot] = n_applied; // :121
     F.upd_head[slot] = 0u; // :121-122
     F.upd_count[slot] = 0u;
     return n_applied;

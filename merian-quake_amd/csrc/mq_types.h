@@ -146,6 +146,7 @@ struct MqParams {
     int32_t enable_albedo_mipmap, enable_emission_mipmap; // g-buffer node, gbuffer.cpp:49-50,79-81
     int32_t debug_output_connected; // DEBUG_OUTPUT_CONNECTED, render_mcpg.cpp:182-183 (selector: debug_output_selector above)
     int32_t freeze_learning; // test hook: every learning computation and RNG draw runs, the stores to MC / LC / distance state do not
+    int32_t lc_lock_protocol; // "debug: LC lock statistics": the reference's per-cell try-lock (light_cache.glsl:59-64,82-83) with its success / cancel counters
     int32_t log_learning;    // test hook: every PROPOSED learning write is appended to MqFrame::learn_log (layouts: include/mq.h, mq_debug_learn_log_read)
     // derived on the host with the same float operations the kernels would use (mq_api.cpp props_to_params)
     float mc_static_inv_width;
@@ -232,6 +233,9 @@ struct MqFrame {
     uint32_t count_stats;  // != 0: kernels without a COUNT instantiation may bump `counters` too
     // traversal stack spill area: MQ_SPILL_ENTRIES 8-byte entries per resident lane
     unsigned long long* stack_spill;
+    // statistics of the reference's dumps (render_mcpg.cpp:354-416), kept only while "debug: LC lock statistics" is set:
+    uint2* lc_stats;          // per light-cache cell: update_succeeded, update_canceled (grid.h:44-45)
+    uint32_t* last_upd_count; // per Markov-chain slot: last_update_count (grid.h:25, compute_updates.comp:121)
     // learning-write log (property "debug: log learning writes"): 64-byte records, count bumped per record
     uint4* learn_log;
     uint32_t* learn_log_count;

@@ -392,8 +392,10 @@ class Context:
     LC_DTYPE = np.dtype([("hash", "<u4"), ("lock", "<u4"), ("irr", "<u2", 3), ("N", "<u2")])
     DIST_DTYPE = np.dtype([("sum_w", "<f4"), ("N", "<u4"), ("m0", "<f4"), ("m1", "<f4")])
 
+    STAT_DTYPES = (np.dtype([("update_succeeded", "<u4"), ("update_canceled", "<u4")]), np.dtype("<u4"))
+
     def state_read(self, which, count):
-        a = np.zeros(count, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE)[which])
+        a = np.zeros(count, (self.MC_DTYPE, self.LC_DTYPE, self.DIST_DTYPE) [which] if which < 3 else self.STAT_DTYPES[which - 3])
         self._chk(self.lib.mq_debug_state_read(self.h, which, a.ctypes.data, a.nbytes))
         return a
 

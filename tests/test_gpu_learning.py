@@ -327,3 +327,46 @@ def test_free_running_learning_frame_replays_in_oracle(gpu_ctx, tables):
     assert len(cells_logged) > 3000
     chk_ok = np.isin((cell << 32) | lc_after["hash"][lcl[:, 14]].astype(np.uint64), (cell << 32) | lcl[:, 0])
     assert chk_ok.all()  # and its key is one of the keys stored (or confirmed) there this frame
+
+
+def test_state_dumps_carry_the_reference_statistics(gpu_ctx, tmp_path):
+    """tools/dump_state.py: mc_dump.json / lc_dump.json / update_buffer_dump.json in the reference's formats
+    (render_mcpg.cpp:322-416) with the statistics its notebooks query (scripts/duckdb queries.md:2-53): updates per slot
+    and frame (last_update_count), light-cache lock successes and cancellations (the cache then runs the reference's
+    try-lock).  The aggregates must agree with what the frame's own counters and log say."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dump_state
+    ctx = gpu_ctx
+    W, H = 160, 96
+    make_pair(ctx, "synth_start", 11, {"reference mode": 0, "spp": 2, "max path length": 3, "debug: LC lock statistics": 1, **SMALL}, W, H)
+    try:
+        for f in range(6):
+            ctx.process(ctx.synth_camera(f))
+        ctx.set_property("debug: log learning writes", 1)
+        ctx.enable_counters(True)
+        ctx.process(ctx.synth_camera(6))
+        cnt = ctx.counters()
+        log = by_kind(ctx.learn_log())
+        summary = dump_state.dump(ctx, str(tmp_path), None)
+    finally:
+        ctx.enable_counters(False)
+        ctx.set_property("debug: log learning writes", 0); ctx.set_property("debug: LC lock statistics", 0)
+    mc = json.load(open(tmp_path / "mc_dump.json")); lc = json.load(open(tmp_path / "lc_dump.json")); ub = json.load(open(tmp_path / "update_buffer_dump.json"))
+    assert len(mc) == SMALL["adaptive grid buf size"] and len(lc) == SMALL["LC buf size"]
+    assert set(mc[0]) == {"id", "N", "hash", "w_cos", "sum_w", "w_tgt", "last_update_count", "tgt_change", "w_change", "cos_change"}
+    assert set(lc[0]) == {"hash", "irr", "N", "update_succeeded", "update_canceled"}
+    # the duckdb queries: light-cache lock outcome ...
+    ok, cancel = sum(c["update_succeeded"] for c in lc), sum(c["update_canceled"] for c in lc)
+    assert ok > 10000 and cancel > 0 and summary["lc_update_succeeded"] == ok and summary["lc_update_canceled"] == cancel
+    # (frame 0 cancels every update -- the zeroed lock word equals the frame number, light_cache.glsl:59-64 -- so cancel > 0 even without contention)
+    # ... and updates per slot: every slot the last frame's log addresses reports min(arrivals, 10); a slot keeps the count of the frame that last touched it
+    upd = log[KIND_UPDATE]
+    per_slot = np.bincount(upd[:, 14], minlength=SMALL["adaptive grid buf size"] + SMALL["static grid buf size"])
+    touched = np.flatnonzero(per_slot[: SMALL["adaptive grid buf size"]])
+    assert len(touched) > 200
+    assert all(mc[int(sl)]["last_update_count"] == min(int(per_slot[sl]), 10) for sl in touched)
+    assert sum(1 for m in mc if m["last_update_count"] > 0) >= len(touched)
+    assert len(ub) == (per_slot > 0).sum() and sum(u["last_update_count"] for u in ub) == cnt["mc_updates_accepted"] == int(np.minimum(per_slot, 10).sum())
+    assert all(len(u["ids"]) == 10 and u["update_count"] == 0 for u in ub)
