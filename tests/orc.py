@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "oracle", "libmqoracle.so")
+LIB = os.environ.get("MQORACLE_LIB") or os.path.join(ROOT, "oracle", "libmqoracle.so")  # MQORACLE_LIB: the sanitizer build (tools/run_sanitized.sh)
 
 (OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_VOLUME, OUT_VOLUME_DEPTH, OUT_VOLUME_MV,
  OUT_DEBUG) = range(10)
