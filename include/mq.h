@@ -144,6 +144,11 @@ int mq_set_property_str(mq_ctx* ctx, const char* key, const char* value);
 int mq_get_property(const mq_ctx* ctx, const char* key, double* value);
 int mq_property_count(void);
 const char* mq_property_name(int index);
+/* what the reference's Properties visitor is called with for this key: MQ_PROP_BOOL config_bool, _INT config_int, _UINT config_uint,
+ * _FLOAT config_float / config_percent / config_angle, _OPTION config_options (its choices: mq_property_option(index, 0..), NULL past the end) */
+enum { MQ_PROP_BOOL = 0, MQ_PROP_INT = 1, MQ_PROP_UINT = 2, MQ_PROP_FLOAT = 3, MQ_PROP_OPTION = 4 };
+int mq_property_type(int index);
+const char* mq_property_option(int index, int option);
 /* load the "properties" object of a node from a merian-quake graph JSON (res/default_config.json
  * layout): node_name e.g. "render_markovchain" or "gbuffer". */
 int mq_load_properties_json(mq_ctx* ctx, const char* json_text, const char* node_name);

@@ -105,43 +105,95 @@ class RendererMarkovChainHIP {
         check(mq_map_output(ctx_, which, &p, bytes));
         return p;
     }
-    // render_mcpg.cpp:419-578: the same visitor serves UI, JSON load and JSON store
-    NodeStatusFlags properties(Properties& config) {
+    // render_mcpg.cpp:419-578: the same visitor serves UI, JSON load and JSON store.  The keys of this node are those without
+    // a node prefix; the ReSTIR node's and the post chain's live under "restir: ", "accum: ", "volume accum: " (adapters below).
+    NodeStatusFlags properties(Properties& config) { return visit_properties(config, ""); }
+
+    // ---- per-frame geometry (QuakeNode::update_dynamic_geo, src/game/quake_node.cpp:896-983): see mq.h "producers" ----
+    void dyn_begin() { check(mq_dyn_begin(ctx_)); }
+    void dyn_add_particles(const mq_particle* p, uint32_t n, const mq_view& view, uint32_t texnum_blood, uint32_t texnum_explosion, double cl_time, double prev_cl_time) {
+        check(mq_dyn_add_particles(ctx_, p, n, &view, texnum_blood, texnum_explosion, cl_time, prev_cl_time));
+    }
+    void dyn_add_alias(int model, const mq_alias_instance& inst) { check(mq_dyn_add_alias(ctx_, model, &inst)); }
+    void dyn_add_sprite(int model, const mq_sprite_instance& inst, const mq_view& view) { check(mq_dyn_add_sprite(ctx_, model, &inst, &view)); }
+    void dyn_add_brush_model(int model, const float origin[3], const float angles[3], const float prev_origin[3], const float prev_angles[3]) {
+        check(mq_dyn_add_brush_model(ctx_, model, origin, angles, prev_origin, prev_angles));
+    }
+    void dyn_end(int slot) { check(mq_dyn_end(ctx_, slot)); scene_dirty_ = true; }
+
+    // shared by the adapters of the other nodes that live on this context
+    NodeStatusFlags visit_properties(Properties& config, const std::string& prefix) {
         bool reconnect = false;
         for (int i = 0; i < mq_property_count(); i++) {
-            const std::string key = mq_property_name(i);
+            const std::string full = mq_property_name(i);
+            const bool prefixed = full.rfind("restir: ", 0) == 0 || full.rfind("accum: ", 0) == 0 || full.rfind("volume accum: ", 0) == 0;
+            if (prefix.empty() ? prefixed : full.rfind(prefix, 0) != 0) continue;
+            const std::string key = full.substr(prefix.size()); // the reference's own key string
             double cur = 0;
-            check(mq_get_property(ctx_, key.c_str(), &cur));
+            check(mq_get_property(ctx_, full.c_str(), &cur));
             double next = cur;
-            if (key == "adaptive grid type" || key == "LC grid type") { int s = (int)cur; config.config_options(key, s, {"exponential", "quadratic"}); next = s; }
-            else if (key == "debug output") { int s = (int)cur; config.config_options(key, s, {"light cache", "mc weight", "mc mean direction", "mc grid", "irradiance", "moments", "mc cos", "mc N", "mc motion vectors"}); next = s; }
-            else if (is_bool(key)) { bool b = cur != 0; config.config_bool(key, b); next = b; }
-            else if (is_uint(key)) { uint32_t u = (uint32_t)cur; config.config_uint(key, u); next = u; }
-            else if (is_int(key)) { int32_t v = (int32_t)cur; config.config_int(key, v); next = v; }
-            else { float f = (float)cur; config.config_float(key, f); next = f; }
-            if (next != cur) { int r = mq_set_property(ctx_, key.c_str(), next); if (r < 0) check(r); reconnect |= r == 1; }
+            switch (mq_property_type(i)) {
+            case MQ_PROP_BOOL: { bool b = cur != 0; config.config_bool(key, b); next = b; break; }
+            case MQ_PROP_INT: { int32_t v = (int32_t)cur; config.config_int(key, v); next = v; break; }
+            case MQ_PROP_UINT: { uint32_t u = (uint32_t)cur; config.config_uint(key, u); next = u; break; }
+            case MQ_PROP_OPTION: {
+                std::vector<std::string> options;
+                for (int k = 0; mq_property_option(i, k); k++) options.push_back(mq_property_option(i, k));
+                int sel = (int)cur; config.config_options(key, sel, options); next = sel; break; }
+            default: { float f = (float)cur; config.config_float(key, f); next = f; break; }
+            }
+            if (next != cur) { int r = mq_set_property(ctx_, full.c_str(), next); if (r < 0) check(r); reconnect |= r == 1; }
         }
         return reconnect ? NEEDS_RECONNECT : NONE;
     }
+    void check_public(int r) { check(r); }
 
   private:
-    static bool is_bool(const std::string& k) {
-        for (const char* b : {"randomize seed", "reference mode", "mc fast recovery", "volume forward project", "surf: use LC", "volume: use LC", "hide sun",
-                              "enable albedo mipmap", "enable emission mipmap", "quirk: LC max(wo_p,10)", "quirk: 16-bit N*N"}) if (k == b) return true;
-        return false;
-    }
-    static bool is_uint(const std::string& k) {
-        for (const char* b : {"seed", "adaptive grid buf size", "static grid buf size", "LC buf size", "dist mc states per vertex"}) if (k == b) return true;
-        return false;
-    }
-    static bool is_int(const std::string& k) {
-        for (const char* b : {"mc samples", "spp", "max path length", "volume spp", "dist mc samples", "dist mc grid width"}) if (k == b) return true;
-        return false;
-    }
     void check(int r) { if (r < 0) throw Error(r, mq_last_error(ctx_)); }
     mq_ctx* ctx_ = nullptr;
     uint32_t width_ = 0, height_ = 0;
     bool scene_dirty_ = false;
+};
+
+// "Renderer (ReSTIR)": RendererRESTIR, src/render_restir/renderer_restir.hpp:35-49, renderer_restir.cpp:56-325.  It consumes the
+// g-buffer node's outputs, which live on the context of the fused GBuffer + MCPG node: the adapter shares that context.
+class RendererRESTIRHIP {
+  public:
+    explicit RendererRESTIRHIP(RendererMarkovChainHIP& gbuffer_node) : g_(gbuffer_node) {}
+    std::vector<std::string> describe_inputs() const { // renderer_restir.cpp:56-62
+        return {"vtx", "prev_vtx", "idx", "ext", "gbuffer", "prev_gbuffer", "hits", "textures", "tlas", "resolution", "render_info", "reservoirs", "mv"};
+    }
+    std::vector<ConnectorDesc> describe_outputs(uint32_t width, uint32_t height) { // renderer_restir.cpp:64-90
+        mq_io_desc d;
+        g_.check_public(mq_describe(g_.handle(), width, height, &d));
+        return {{"irradiance", "R32G32B32A32Sfloat", d.bytes[MQ_OUT_RESTIR_IRRADIANCE]}, {"moments", "R32G32Sfloat", d.bytes[MQ_OUT_RESTIR_MOMENTS]},
+                {"reservoirs", "ReSTIRDIReservoir64B", d.bytes[MQ_OUT_RESTIR_RESERVOIRS]}};
+    }
+    NodeStatusFlags on_connected() { return NONE; } // the shared context allocates the node's buffers with its own (renderer_restir.cpp:92-107)
+    void process(const RenderInfo& info, void* hip_stream) { g_.check_public(mq_restir_process(g_.handle(), &info.uniform, info.render ? 1 : 0, hip_stream)); } // :109-251, after the g-buffer node's process
+    NodeStatusFlags properties(Properties& config) { return g_.visit_properties(config, "restir: "); }                                                          // :253-325
+  private:
+    RendererMarkovChainHIP& g_;
+};
+
+// The graph's "accum" / "volume accum" (merian Accumulate) nodes, the denoiser's albedo re-modulation and "add"
+// (res/default_config.json:21-133,404-435,473-497) as one post step on the same context: mq_post_process.
+class PostChainHIP {
+  public:
+    explicit PostChainHIP(RendererMarkovChainHIP& renderer) : g_(renderer) {}
+    std::vector<ConnectorDesc> describe_outputs(uint32_t width, uint32_t height) {
+        mq_io_desc d;
+        g_.check_public(mq_describe(g_.handle(), width, height, &d));
+        return {{"accum.out", "R32G32B32A32Sfloat", d.bytes[MQ_OUT_ACCUM]}, {"accum.history", "R32Sfloat", d.bytes[MQ_OUT_ACCUM_HISTORY]},
+                {"volume accum.out", "R32G32B32A32Sfloat", d.bytes[MQ_OUT_VOLUME_ACCUM]}, {"volume accum.history", "R32Sfloat", d.bytes[MQ_OUT_VOLUME_ACCUM_HISTORY]},
+                {"add.out", "R32G32B32A32Sfloat", d.bytes[MQ_OUT_FINAL]}};
+    }
+    void process(void* hip_stream) { g_.check_public(mq_post_process(g_.handle(), hip_stream)); }
+    void clear() { g_.check_public(mq_post_clear(g_.handle())); } // the nodes' "clear event pattern"
+    NodeStatusFlags properties_accum(Properties& config) { return g_.visit_properties(config, "accum: "); }
+    NodeStatusFlags properties_volume_accum(Properties& config) { return g_.visit_properties(config, "volume accum: "); }
+  private:
+    RendererMarkovChainHIP& g_;
 };
 
 } // namespace mq

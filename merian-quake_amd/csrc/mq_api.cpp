@@ -495,6 +495,11 @@ const char* mq_last_error(const mq_ctx* c) { return c ? c->err.c_str() : "null c
 // ---- properties --------------------------------------------------------------------------------
 int mq_property_count(void) { return k_nprops; }
 const char* mq_property_name(int i) { return (i >= 0 && i < k_nprops) ? k_props[i].key : nullptr; }
+int mq_property_type(int i) {
+    if (i < 0 || i >= k_nprops) return MQ_EINVAL;
+    switch (k_props[i].type) { case PT_BOOL: return MQ_PROP_BOOL; case PT_INT: return MQ_PROP_INT; case PT_UINT: return MQ_PROP_UINT; case PT_FLOAT: return MQ_PROP_FLOAT; default: return MQ_PROP_OPTION; }
+}
+const char* mq_property_option(int i, int k) { return (i >= 0 && i < k_nprops && k >= 0 && k < 10) ? k_props[i].options[k] : nullptr; }
 
 int mq_set_property(mq_ctx* c, const char* key, double value) {
     if (!c || !key) return MQ_EINVAL;

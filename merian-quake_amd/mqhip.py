@@ -107,6 +107,8 @@ def load_library(path=None):
         "mq_get_property": (i32, [P, C.c_char_p, C.POINTER(C.c_double)]),
         "mq_property_count": (i32, []),
         "mq_property_name": (C.c_char_p, [i32]),
+        "mq_property_type": (i32, [i32]),
+        "mq_property_option": (C.c_char_p, [i32, i32]),
         "mq_load_properties_json": (i32, [P, C.c_char_p, C.c_char_p]),
         "mq_properties_header_defaults": (None, [P]),
         "mq_properties_json_defaults": (None, [P]),

@@ -33,7 +33,9 @@ int main() {
     Loader l;
     l.vals["spp"] = 2; l.vals["BSDF Prob"] = 0.1; l.vals["reference mode"] = 0; l.vals["seed"] = 1234; l.vals["randomize seed"] = 0;
     REQUIRE(node.properties(l) == mq::NONE);          // only pipeline-refresh class changes
-    REQUIRE(l.visited == mq_property_count());
+    int own = 0; // the fused node's own keys: those without a "restir: " / "accum: " / "volume accum: " prefix
+    for (int i = 0; i < mq_property_count(); i++) { std::string k = mq_property_name(i); if (k.rfind("restir: ", 0) && k.rfind("accum: ", 0) && k.rfind("volume accum: ", 0)) own++; }
+    REQUIRE(l.visited == own);
     double v = 0; mq_get_property(node.handle(), "spp", &v); REQUIRE(v == 2);
     mq_get_property(node.handle(), "BSDF Prob", &v); REQUIRE(v > 0.0999 && v < 0.1001);
     Loader l2; l2.opts["LC grid type"] = "quadratic"; l2.vals["LC buf size"] = 4000037;
@@ -49,6 +51,25 @@ int main() {
     threw = false;
     mq::RenderInfo info;
     try { node.process(info, nullptr); } catch (const mq::Error& e) { threw = e.code == MQ_ENODEVICE; }
+    REQUIRE(threw);
+    // the ReSTIR node and the post chain on the same context: the reference's own key strings, prefix stripped
+    mq::RendererRESTIRHIP restir(node);
+    REQUIRE(restir.describe_inputs().size() == 13);
+    auto routs = restir.describe_outputs(1920, 1080);
+    REQUIRE(routs.size() == 3 && routs[2].name == "reservoirs" && routs[2].bytes == 1920u * 1080u * 64u);
+    Loader l3; l3.vals["spp"] = 3; l3.vals["enable temporal reuse"] = 1; l3.opts["temporal bias correction"] = "raytraced"; l3.vals["spatital radius"] = 12;
+    REQUIRE(restir.properties(l3) == mq::NONE);
+    REQUIRE(l3.visited == 16);
+    mq_get_property(node.handle(), "restir: spp", &v); REQUIRE(v == 3);
+    mq_get_property(node.handle(), "restir: temporal bias correction", &v); REQUIRE(v == 2);
+    mq_get_property(node.handle(), "spp", &v); REQUIRE(v == 2); // the MCPG node's "spp" is another property
+    mq::PostChainHIP post(node);
+    Loader l4; l4.vals["alpha"] = 0.5;
+    REQUIRE(post.properties_accum(l4) == mq::NONE && l4.visited == 6);
+    mq_get_property(node.handle(), "accum: alpha", &v); REQUIRE(v == 0.5);
+    mq_get_property(node.handle(), "volume accum: alpha", &v); REQUIRE(v > 0.9 && v < 0.91);
+    threw = false;
+    try { restir.process(info, nullptr); } catch (const mq::Error& e) { threw = e.code == MQ_ENODEVICE; }
     REQUIRE(threw);
     printf("node adapter ok\n");
     return 0;
