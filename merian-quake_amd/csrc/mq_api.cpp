@@ -31,7 +31,7 @@ int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, uint32_t sequ
 int mq_launch_debug_view(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_stack_lds_entries();
 int mq_launch_stream_read(const void* src, size_t bytes, uint32_t* sink, int grid, hipStream_t s);
-int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int out[3]);
+int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int shade_block, int out[3]);
 int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
 int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s);
@@ -505,7 +505,7 @@ int mq_set_property(mq_ctx* c, const char* key, double value) {
     if (!c || !key) return MQ_EINVAL;
     const PropDesc* d = find_prop(key);
     if (!d) return fail(c, MQ_EUNKNOWN_KEY, std::string("unknown property: ") + key);
-    if (!strcmp(key, "mc samples") && (value < 0 || value > MQ_MAX_MC_SAMPLES)) return fail(c, MQ_EINVAL, "mc samples must be in [0, 8] in this build");
+    if ((!strcmp(key, "mc samples") || !strcmp(key, "dist mc samples")) && (value < 0 || value > MQ_MAX_MC_SAMPLES)) return fail(c, MQ_EINVAL, std::string(key) + " must be in [0, 30] (render_mcpg.cpp:460,494)");
     if (d->type == PT_OPTION) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
     bool changed = prop_set(c->props, *d, value);
     if (changed) c->params_dirty = true;
@@ -964,7 +964,10 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     F.lc_stats = (uint2*)c->d_lc_stats.p; F.last_upd_count = (uint32_t*)c->d_last_upd.p;
     F.learn_log = (uint4*)c->d_learn_log.p; F.learn_log_count = (uint32_t*)c->d_learn_count.p; F.learn_log_cap = c->learn_log_cap;
     const int K = c->params.reference_mode ? 0 : std::max(0, c->params.mc_samples);
-    F.lds_rows2 = (uint32_t)std::max(mq_stack_lds_entries(), (6 * K + 1) / 2);
+    const int KD = c->params.reference_mode || c->params.volume_spp <= 0 ? 0 : std::max(0, c->params.distance_mc_samples);
+    F.lds_rows2 = (uint32_t)std::max(mq_stack_lds_entries(), std::max((6 * K + 1) / 2, (3 * KD + 1) / 2));
+    F.shade_block = (uint32_t)mq_render_block_size();
+    while (F.shade_block > 64 && (size_t)F.lds_rows2 * 64 * 8 * (F.shade_block / 64) > 64 * 1024) F.shade_block /= 2; // a block's LDS: at most 64 KB
 }
 
 #ifndef MQ_GRID_MODE
@@ -977,13 +980,13 @@ static int frame_grids(mq_ctx* c, const MqFrame& F) {
     const int key = (int)F.lds_rows2 * 2 + (c->params.reference_mode ? 1 : 0);
     if (c->grid_key == key) return MQ_OK;
     int occ[3] = {0, 0, 0};
-    int e = mq_resident_blocks(!c->params.reference_mode, (size_t)F.lds_rows2 * 64 * 8 * (mq_render_block_size() / 64), occ);
+    int e = mq_resident_blocks(!c->params.reference_mode, (size_t)F.lds_rows2 * 64 * 8 * (F.shade_block / 64), (int)F.shade_block, occ);
     if (e) return fail(c, MQ_EHIP, std::string("occupancy query: ") + hipGetErrorString((hipError_t)e));
     for (int i = 0; i < 3; i++) {
 #if MQ_GRID_MODE == 0
         c->grid_frame[i] = c->grid_blocks;
 #else
-        c->grid_frame[i] = std::min(c->grid_blocks, std::max(1, c->cu_count) * std::max(1, occ[i]));
+        c->grid_frame[i] = std::min(i == 1 ? c->grid_blocks : c->grid_blocks * (mq_render_block_size() / (int)F.shade_block), std::max(1, c->cu_count) * std::max(1, occ[i])); // (smaller shading blocks: more of them, the same number of threads at most)
 #endif
         static const char* const names[3] = {"MQ_DEBUG_PRIMARY_BLOCKS_PER_CU", "MQ_DEBUG_TRACE_BLOCKS_PER_CU", "MQ_DEBUG_BOUNCE_BLOCKS_PER_CU"};
         if (const char* ev = getenv(names[i])) { int v = atoi(ev); if (v > 0) c->grid_frame[i] = std::min(c->grid_blocks, std::max(1, c->cu_count) * v); } // tuning experiments only

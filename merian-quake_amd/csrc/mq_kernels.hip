@@ -1192,17 +1192,17 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint2* stk = s_dyn + (size_t)wave * F.lds_rows2 * 64 + lane;
     float* lobes = GUIDED ? (float*)(s_dyn + (size_t)wave * F.lds_rows2 * 64) + lane : nullptr;
-    unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * MQ_BLOCK + threadIdx.x) * MQ_SPILL_ENTRIES;
+    unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * MQ_SPILL_ENTRIES; // blockDim.x: 256, fewer when many Markov-chain samples need more LDS per wave (shade_block)
     const uint32_t total = F.slot_end; // this pipeline's pixel slots: [slot_begin, slot_end)
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
     const f3 gb_sun = P.gbuffer_hide_sun ? F3(0.0f, 0.0f, 0.0f) : F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
-    const uint32_t stride = gridDim.x * MQ_BLOCK;
+    const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (total - F.slot_begin + stride - 1) / stride;
     PSTART(ctr);
     for (uint32_t it = 0; it < rounds; it++) {
-        const uint32_t my = F.slot_begin + it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        const uint32_t my = F.slot_begin + it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool cont = false;
         Path p = {};
         PLAP(ctr, 0);
@@ -1509,11 +1509,11 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
     const uint32_t n = qv.n_eff;
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
-    const uint32_t stride = gridDim.x * MQ_BLOCK;
+    const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t iters = (n + stride - 1) / stride;
     PSTART(ctr);
     for (uint32_t it = 0; it < iters; it++) {
-        const uint32_t q = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        const uint32_t q = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool cont = false;
         uint32_t slot = 0;
         Path p = {};
@@ -1656,8 +1656,8 @@ __global__ void mq_forward_project_kernel(MqParams P, MqFrame F) { // volume_for
 // camera-distance sampling + direction choice (volume.comp:54-179) for sample `smp` of every pixel
 template <bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kernel(MqSceneDev sc, MqParams P, MqFrame F, int smp, int round) {
-    __shared__ float s_lobes[MQ_WAVES][6 * MQ_MAX_MC_SAMPLES][64];
-    float* lobes = &s_lobes[threadIdx.x >> 6][0][threadIdx.x & 63];
+    extern __shared__ uint2 s_dyn[]; // F.lds_rows2 rows of 64 x 8 bytes per wave: the candidates' (score, mu, sigma), then the lobes
+    float* lobes = (float*)(s_dyn + (size_t)(threadIdx.x >> 6) * F.lds_rows2 * 64) + (threadIdx.x & 63);
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
     const uint32_t total = F.n_local_tiles * 64u;
@@ -1666,10 +1666,10 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kerne
     const int KD = P.distance_mc_samples < MQ_MAX_MC_SAMPLES ? P.distance_mc_samples : MQ_MAX_MC_SAMPLES;
     const int K = P.mc_samples < MQ_MAX_MC_SAMPLES ? P.mc_samples : MQ_MAX_MC_SAMPLES;
     Ctr ctr = {};
-    const uint32_t stride = gridDim.x * MQ_BLOCK;
+    const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t iters = (total + stride - 1) / stride;
     for (uint32_t it = 0; it < iters; it++) {
-        const uint32_t my = it * stride + blockIdx.x * MQ_BLOCK + threadIdx.x;
+        const uint32_t my = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         bool cont = false;
         VPath v = {};
         f3 first_wi = F3(0, 0, 1);
@@ -2124,12 +2124,12 @@ __global__ void mq_math_kernel(MqSceneDev sc, MqParams P, int op, int ni, int no
 // host-callable launchers (C++ linkage; used by mq_api.cpp)
 // ------------------------------------------------------------------------------------------------
 // dynamic LDS bytes of a shading block: F.lds_rows2 rows of 64 x 8 bytes per wave
-static size_t shade_lds(const MqFrame& F) { return (size_t)F.lds_rows2 * 64 * 8 * MQ_WAVES; }
+static size_t shade_lds(const MqFrame& F) { return (size_t)F.lds_rows2 * 64 * 8 * (F.shade_block / 64); }
 int mq_launch_primary(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool guided, bool count, int grid, hipStream_t s) {
     const size_t lds = shade_lds(F);
 
-    if (guided) { if (count) mq_primary_kernel<true, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); else mq_primary_kernel<true, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); }
-    else { if (count) mq_primary_kernel<false, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); else mq_primary_kernel<false, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F); }
+    if (guided) { if (count) mq_primary_kernel<true, true><<<grid, F.shade_block, lds, s>>>(sc, P, F); else mq_primary_kernel<true, false><<<grid, F.shade_block, lds, s>>>(sc, P, F); }
+    else { if (count) mq_primary_kernel<false, true><<<grid, F.shade_block, lds, s>>>(sc, P, F); else mq_primary_kernel<false, false><<<grid, F.shade_block, lds, s>>>(sc, P, F); }
     return (int)hipGetLastError();
 }
 int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, bool packet, int grid, hipStream_t s) {
@@ -2144,8 +2144,8 @@ int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, boo
 }
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s) {
     const size_t lds = guided ? shade_lds(F) : 0;
-    if (guided) { if (count) mq_bounce_kernel<true, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); else mq_bounce_kernel<true, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); }
-    else { if (count) mq_bounce_kernel<false, true><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); else mq_bounce_kernel<false, false><<<grid, MQ_BLOCK, lds, s>>>(sc, P, F, round); }
+    if (guided) { if (count) mq_bounce_kernel<true, true><<<grid, F.shade_block, lds, s>>>(sc, P, F, round); else mq_bounce_kernel<true, false><<<grid, F.shade_block, lds, s>>>(sc, P, F, round); }
+    else { if (count) mq_bounce_kernel<false, true><<<grid, F.shade_block, lds, s>>>(sc, P, F, round); else mq_bounce_kernel<false, false><<<grid, F.shade_block, lds, s>>>(sc, P, F, round); }
     return (int)hipGetLastError();
 }
 int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, uint32_t sequential_mc_total, hipStream_t s) {
@@ -2179,7 +2179,8 @@ int mq_launch_forward_project(const MqParams& P, const MqFrame& F, int grid, hip
     return (int)hipGetLastError();
 }
 int mq_launch_volume_sample(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s) {
-    if (count) mq_volume_sample_kernel<true><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, smp, round); else mq_volume_sample_kernel<false><<<grid, MQ_BLOCK, 0, s>>>(sc, P, F, smp, round);
+    const size_t lds = shade_lds(F);
+    if (count) mq_volume_sample_kernel<true><<<grid, F.shade_block, lds, s>>>(sc, P, F, smp, round); else mq_volume_sample_kernel<false><<<grid, F.shade_block, lds, s>>>(sc, P, F, smp, round);
     return (int)hipGetLastError();
 }
 int mq_launch_volume_shade(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s) {
@@ -2214,16 +2215,16 @@ int mq_render_block_size() { return MQ_BLOCK; }
 int mq_spill_entries() { return MQ_SPILL_ENTRIES; }
 int mq_stack_lds_entries() { return MQ_STACK_LDS; }
 // resident blocks per CU of the three frame kernels at the given dynamic LDS size: {primary, trace, bounce}
-int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int out[3]) {
+int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int shade_block, int out[3]) {
     int a = 0, b = 0, c = 0;
     hipError_t e;
-    if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<true, false>, MQ_BLOCK, shade_lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<false, false>, MQ_BLOCK, shade_lds_bytes);
+    if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<true, false>, shade_block, shade_lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<false, false>, shade_block, shade_lds_bytes);
     if (e != hipSuccess) return (int)e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false>, MQ_BLOCK, 0);
     if (e != hipSuccess) return (int)e;
-    if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<true, false>, MQ_BLOCK, shade_lds_bytes);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<false, false>, MQ_BLOCK, 0);
+    if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<true, false>, shade_block, shade_lds_bytes);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<false, false>, shade_block, 0);
     if (e != hipSuccess) return (int)e;
     out[0] = a; out[1] = b; out[2] = c;
     return 0;

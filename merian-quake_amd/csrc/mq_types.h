@@ -20,7 +20,7 @@
 #define MQ_LC_MAX_N 128            // light_cache.glsl:1
 #define MQ_LC_MIN_ALPHA 0.01f      // light_cache.glsl:2
 #define MQ_MAX_UPDATES 10          // grid.h:29-34
-#define MQ_MAX_MC_SAMPLES 8        // kernel register budget; reference UI allows 0..30
+#define MQ_MAX_MC_SAMPLES 30       // the reference's range of "mc samples" / "dist mc samples" (render_mcpg.cpp:460,494); the lobes live in LDS sized at run time
 #define MQ_BARY_EPS 3.814697265625e-06f
 #define MQ_NIL 0xffffffffu
 #define MQ_WIDTH_LUT 48
@@ -242,6 +242,7 @@ struct MqFrame {
     uint32_t learn_log_cap;
     // dynamic LDS of the shading kernels: 8-byte rows of 64 lanes per wave (lobe storage: 3 rows per Markov-chain sample)
     uint32_t lds_rows2;
+    uint32_t shade_block;  // threads per block of the kernels that keep lobes in LDS: 256, or fewer when lds_rows2 rows per wave would not fit four waves into a block's LDS
 };
 
 // ---- ReSTIR DI node (mq_restir.h) ----

@@ -515,13 +515,17 @@ def _copy_learned_state(ctx, o, with_distance=False):
     return gmc, glc
 
 
-def test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx):
+@pytest.mark.parametrize("samples", [None, (30, 30), (7, 30)])
+def test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx, samples):
     """The same for a config-4 style frame: surface guiding + single-scatter volume estimator with its distance and
-    direction Markov chains (volume.comp:34-238), from the oracle's learned state, stores switched off."""
+    direction Markov chains (volume.comp:34-238), from the oracle's learned state, stores switched off.  `samples`:
+    ("mc samples", "dist mc samples") up to the top of the reference's range (render_mcpg.cpp:460,494: 0..30), where the
+    shading blocks shrink to one wave so that a wave's lobes still fit into LDS."""
     import mqhip
     ctx = gpu_ctx
     W, H = 112, 72
-    o = make_pair(ctx, "synth_start_fog", 7, {"reference mode": 0, "spp": 1, "max path length": 3, **VOL, "volume forward project": 0}, W, H)  # forward projection would feed the previous frame's learned depth in
+    more = {} if samples is None else {"mc samples": samples[0], "dist mc samples": samples[1]}
+    o = make_pair(ctx, "synth_start_fog", 7, {"reference mode": 0, "spp": 1, "max path length": 3, **VOL, "volume forward project": 0, **more}, W, H)  # forward projection would feed the previous frame's learned depth in
     for f in range(5):
         o.process(ctx.synth_camera(f), threads=1)
     for f in range(5):  # the device renders the same frames so that its delay-1 inputs (previous volume depth) exist
@@ -580,7 +584,8 @@ def test_debug_views_match_oracle(gpu_ctx):
         ctx.set_property("debug output connected", 0)
 
 
-def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx):
+@pytest.mark.parametrize("mc_samples", [None, 12, 30])
+def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx, mc_samples):
     """The WHOLE guided estimator (K Markov-chain lookups with validation and motion extrapolation, lobe selection,
     vMF / BSDF sampling, the MIS pdf mixture, light-cache reads, the learning computations and their RNG draws) is
     deterministic once the learning state is given and its stores are switched off: the oracle learns for a few
@@ -589,6 +594,8 @@ def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx):
     ctx = gpu_ctx
     W, H = 128, 80
     props = {"reference mode": 0, "spp": 2, "max path length": 3, **SMALL}
+    if mc_samples is not None:  # the reference's range is 0..30 (render_mcpg.cpp:460)
+        props["mc samples"] = mc_samples
     o = make_pair(ctx, "synth_start", 11, props, W, H)
     for f in range(5):  # the oracle learns (sequential frame: deterministic)
         o.process(ctx.synth_camera(f), threads=1)
