@@ -90,6 +90,7 @@ struct mq_ctx {
     uint32_t n_local_tiles = 0, tiles_per_rank = 0;
     DevBuf d_out[MQ_OUT_COUNT];
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
+    bool queues_dirty = true;      // the ray-queue control words have to be zeroed before the next frame uses them
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
     DevBuf d_prev_vdepth, d_dist_mc;
     DevBuf d_restir_pong, d_restir_prev, d_restir_prev_gb; // ReSTIR: ping-pong partner of the "reservoirs" output, last frame's reservoirs and g-buffer (the graph's delay-1 inputs)
@@ -273,7 +274,7 @@ const PropDesc k_props[] = {
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
-    {"overlap camera rays", PT_BOOL, POFF(overlap_camera_rays), false, {}},
+    {"overlap camera rays", PT_OPTION, POFF(overlap_camera_rays), false, {"off", "partitioned frames", "always"}},
     {"camera rays: frustum packets", PT_BOOL, POFF(packet_camera_rays), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
@@ -465,7 +466,12 @@ int mq_create(mq_ctx** out, int device) {
         bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; ok && k < mq_ctx::MAX_SUBS - 1; k++)
             ok = hipStreamCreateWithFlags(&c->side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&c->pt_stream, hipStreamNonBlocking) == hipSuccess;
+        { // its own hardware queue: streams of one priority share a small pool of queues round robin (this one landed on the
+          // caller's queue and its launches ran in line with the frame); a lower priority has its own pool, and fill-in work is what it is
+            int least = 0, greatest = 0;
+            ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+            ok = ok && hipStreamCreateWithPriority(&c->pt_stream, hipStreamNonBlocking, least) == hipSuccess;
+        }
         for (int k = 0; ok && k < 2; k++) ok = hipEventCreateWithFlags(&c->ev_pt_done[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_shaded[k], hipEventDisableTiming) == hipSuccess;
         for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) ok = ok && hipEventCreate(&e4) == hipSuccess;
         if (!ok) { delete c; return MQ_EHIP; }
@@ -868,6 +874,7 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     c->queue_cap = (uint32_t)std::min<size_t>(queue_entries_needed(c), 0x7fffffffu);
     if ((r = dev_alloc(c, c->d_queue, (size_t)c->queue_cap * sizeof(MqUpdate)))) return r;
     c->subs = std::min(std::max(1, c->props.pipelines), (int)mq_ctx::MAX_SUBS);
+    c->queues_dirty = true;
     if ((r = dev_alloc(c, c->d_ctrl, (size_t)c->subs * MQ_CTRL_WORDS * 4))) return r; // block 0: the rank's (flags, update tails) + sub 0's queues; block k: sub k's queues
     if ((r = dev_alloc(c, c->d_counters, sizeof(MqCountersDev)))) return r;
     HIPCHK(c, hipMemset(c->d_counters.p, 0, sizeof(MqCountersDev)));
@@ -949,7 +956,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     F.gb_albedo = (uint16_t*)c->d_out[MQ_OUT_GB_ALBEDO].p; F.gb_irr = (uint16_t*)c->d_out[MQ_OUT_GB_IRRADIANCE].p;
     F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
-    F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.counters = (MqCountersDev*)c->d_counters.p; F.count_stats = c->count_enabled ? 1u : 0u;
+    F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.ctrl_words = (uint32_t)(c->d_ctrl.bytes / 4); F.counters = (MqCountersDev*)c->d_counters.p; F.count_stats = c->count_enabled ? 1u : 0u;
     const size_t k = sub < 0 ? 0 : (size_t)sub, qoff = k * c->sub_ray_cap;
     F.slot_begin = sub < 0 ? 0u : c->sub_slot_begin[sub]; F.slot_end = sub < 0 ? c->n_local_tiles * 64u : c->sub_slot_begin[sub + 1];
     F.qctrl = F.ctrl + k * MQ_CTRL_WORDS;
@@ -1055,7 +1062,10 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
         return MQ_OK;
     }
-    HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_QUEUE0, 0, ((size_t)c->subs * MQ_CTRL_WORDS - MQ_CTRL_QUEUE0) * 4, s)); // queue counters of every sub-pipeline; the update tail survives (volume-pass entries of the last frame)
+    // queue counters of every sub-pipeline; the update tail survives (volume-pass entries of the last frame).  After a guided
+    // frame without volume passes the update pass has left them zero already (reset_queue_control).
+    if (c->queues_dirty) HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_QUEUE0, 0, ((size_t)c->subs * MQ_CTRL_WORDS - MQ_CTRL_QUEUE0) * 4, s));
+    c->queues_dirty = true;
     if (c->count_enabled) HIPCHK(c, hipMemsetAsync(c->d_counters.p, 0, offsetof(MqCountersDev, prof), s));
     const bool guided = !c->params.reference_mode;
     // rounds: every sample needs at most (max_path_length - 1) traced segments, render_mcpg.cpp:142-143
@@ -1086,7 +1096,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     // The camera rays of this frame do not wait for the previous frame: the host runs ahead of the device, so this
     // launch executes beside the previous frame's kernels and fills the tails of their launches.  It waits only for
     // the first-hit kernel that last read the hit buffer of this parity (two frames ago).
-    const bool overlap_pt = c->props.overlap_camera_rays && !c->count_enabled;
+    const bool overlap_pt = (c->props.overlap_camera_rays == 2 || (c->props.overlap_camera_rays == 1 && c->world > 1)) && !c->count_enabled;
     const uint32_t parity = c->frame_parity & 1u;
     c->ev_pt_timed[slot] = overlap_pt && detail;
     if (overlap_pt) {
@@ -1140,7 +1150,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     }
     // ---- volume passes, render_mcpg.cpp:280-320 (their device time is part of the update interval) ----
-    if (guided) HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_UPDATES, 0, 4 * MQ_CTRL_GROUP, s)); // queue consumed; volume entries start at 0
+    if (guided) c->queues_dirty = volume; // the update pass zeroed the control words of every queue (reset_queue_control): volume entries start at 0
     if (volume) {
         const size_t px = (size_t)c->W * c->H;
         HIPCHK(c, hipMemcpyAsync(c->d_prev_vdepth.p, c->d_out[MQ_OUT_VOLUME_DEPTH].p, px * 2, hipMemcpyDeviceToDevice, s)); // delay-1 feedback connector

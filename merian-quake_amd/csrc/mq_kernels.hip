@@ -968,10 +968,10 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
 // appends to the shard of its wave id with ONE atomic (ballot + prefix popcount).  Consumers walk
 // positions [0, n_eff) and skip the holes behind shorter shards.
 struct QView { uint32_t cnt; uint32_t n_eff; }; // cnt: tail of shard (lane & 15) in every lane; n_eff = 1024 * ceil(max tail / 64)
-MQ_DEV QView queue_view(const uint32_t* tails) {
+MQ_DEV QView queue_view(const uint32_t* tails, uint32_t stride = MQ_SHARD_STRIDE) {
     const int lane = threadIdx.x & 63;
     QView v;
-    v.cnt = tails[(lane & (MQ_SHARDS - 1)) * MQ_SHARD_STRIDE];
+    v.cnt = tails[(lane & (MQ_SHARDS - 1)) * stride];
     uint32_t m = v.cnt;
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
@@ -1883,6 +1883,7 @@ MQ_DEV void mc_update(MCS& s, f3 pos, float w, f3 target, const uint16_t* mv) { 
 // pass A: chain the queue entries of each slot (newest first) through `next`
 __global__ __launch_bounds__(256) void mq_link_kernel(MqFrame F) {
     const QView qv = queue_view(F.ctrl + MQ_CTRL_UPDATES);
+    if (blockIdx.x == 0 && threadIdx.x < MQ_SHARDS) F.ctrl[MQ_CTRL_SNAP + threadIdx.x] = F.ctrl[MQ_CTRL_UPDATES + threadIdx.x * MQ_SHARD_STRIDE];
     const uint32_t n = qv.n_eff < F.queue_cap ? qv.n_eff : F.queue_cap;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
@@ -1950,10 +1951,18 @@ MQ_DEV uint32_t apply_slot(const MqParams& P, const MqFrame& F, uint32_t slot, u
     return n_applied;
 }
 
+// The apply pass reads the update-queue tails from the snapshot the link pass left (MQ_CTRL_SNAP), so its first block
+// can zero the live control words of every queue of the frame right away -- the ray queues were consumed by the bounce
+// kernels before it, the update queue is being consumed by this pass -- and the next frame needs no fill launch.  (A
+// "last block done" counter would do too, but 2048 blocks bumping one address cost +70 us on this eight-die part.)
+MQ_DEV void reset_queue_control(const MqFrame& F) {
+    if (blockIdx.x == 0) for (uint32_t w = MQ_CTRL_UPDATES + threadIdx.x; w < F.ctrl_words; w += blockDim.x) F.ctrl[w] = 0u;
+}
+
 // pass B: the newest entry of a slot leads and replays compute_updates.comp:56-124 for the slot's
 // first MQ_MAX_UPDATES arrivals (the reference drops later arrivals at enqueue time, mc.glsl:169-184)
 __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
-    const QView qv = queue_view(F.ctrl + MQ_CTRL_UPDATES);
+    const QView qv = queue_view(F.ctrl + MQ_CTRL_SNAP, 1u);
     const uint32_t n = qv.n_eff < F.queue_cap ? qv.n_eff : F.queue_cap;
     uint32_t accepted = 0;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -1969,6 +1978,7 @@ __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
     // statistics: updates applied this frame (those dropped by the cap are counted where they are dropped, at enqueue)
     for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);
     if (F.count_stats && (threadIdx.x & 63) == 0 && accepted) atomicAdd(&F.counters->mc_updates_accepted, (unsigned long long)accepted);
+    reset_queue_control(F);
 }
 
 // The same pass in the reference's own dispatch order, serialised (property "debug: sequential update pass", a test
@@ -1989,6 +1999,7 @@ __global__ __launch_bounds__(64) void mq_apply_seq_kernel(MqParams P, MqFrame F,
         }
     }
     if (F.count_stats && lane == 0 && accepted) atomicAdd(&F.counters->mc_updates_accepted, (unsigned long long)accepted);
+    reset_queue_control(F);
 }
 
 // ------------------------------------------------------------------------------------------------

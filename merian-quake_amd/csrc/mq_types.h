@@ -31,6 +31,7 @@
 #define MQ_SHARD_STRIDE 32                                  // words between the counters of two shards (128 B)
 #define MQ_MAX_ROUNDS 30
 #define MQ_CTRL_GROUP (MQ_SHARDS * MQ_SHARD_STRIDE)         // words of one sharded counter
+#define MQ_CTRL_SNAP 32                                     // the update-queue tails as the link pass saw them (16 words, one per shard): what the apply pass reads
 #define MQ_CTRL_UPDATES MQ_CTRL_GROUP                       // update-queue tails (group 1; group 0 holds the overflow flag)
 #define MQ_CTRL_QUEUE0 (2 * MQ_CTRL_GROUP)                  // ray-queue tails, one group per round
 #define MQ_CTRL_HEAD0 (MQ_CTRL_QUEUE0 + (MQ_MAX_ROUNDS + 1) * MQ_CTRL_GROUP) // traversal fetch heads (64-entry blocks), one group per round
@@ -219,6 +220,7 @@ struct MqFrame {
     // ctrl: the rank's block (overflow flags, update-queue tails); qctrl: the block of this launch's sub-pipeline (its
     // ray-queue tails and fetch heads per round)
     uint32_t* ctrl;
+    uint32_t ctrl_words;   // all control words of the rank (every sub-pipeline's block)
     uint32_t* qctrl;
     // wavefront state: 160-byte path records per pixel slot, rays / hits per queue position,
     // ping-pong queues of pixel slots

@@ -1,0 +1,85 @@
+"""Scheduling options of this build (no reference counterpart: "pipelines", "overlap camera rays", the rank partition)
+decide WHEN launches run, never what they compute: the node outputs are bit-identical for every setting, in reference
+mode and for guided frames rendered from a given (frozen) learning state."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SMALL = {"adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16}
+SETTINGS = [(1, "off"), (2, "off"), (4, "off"), (1, "always"), (3, "always")]
+
+
+def _outputs(ctx):
+    import mqhip
+    names = ("OUT_IRRADIANCE", "OUT_GB_ALBEDO", "OUT_GB_IRRADIANCE", "OUT_GB_MV", "OUT_GBUFFER", "OUT_HITS")
+    return {n: ctx.read_output(getattr(mqhip, n)).copy() for n in names}
+
+
+def _render(mqlib, props, pipelines, overlap, frames, sync_every_frame, learned=None, partition=None):
+    import mqhip
+    ctx = mqhip.Context(0)
+    ctx.header_defaults()
+    ctx.synth_scene("synth_start", 4)
+    for k, v in {"randomize seed": 0, "seed": 0x5EED, **SMALL, **props, "pipelines": pipelines, "overlap camera rays": overlap}.items():
+        ctx.set_property(k, v)
+    ctx.commit()
+    if partition:
+        ctx.set_partition(*partition)
+    ctx.connect(328, 200)
+    ctx.process(ctx.synth_camera(0))
+    if learned is not None:
+        ctx.state_write(0, learned[0]); ctx.state_write(1, learned[1])
+        ctx.set_property("debug: freeze learning", 1)
+    for f in range(1, frames):
+        ctx.process(ctx.synth_camera(f))   # the host runs ahead of the device unless something reads
+        if sync_every_frame:
+            ctx.sync()
+    out = _outputs(ctx)
+    assert ctx.counters()["queue_overflow"] == 0
+    ctx.close()
+    return out
+
+
+def _same(a, b, what):
+    assert a.keys() == b.keys() and len(a) >= 2
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (what, k)
+
+
+@pytest.mark.parametrize("sync_every_frame", [False, True])
+def test_reference_mode_outputs_do_not_depend_on_scheduling(mqlib, sync_every_frame):
+    props = {"reference mode": 1, "spp": 2, "max path length": 3}
+    base = _render(mqlib, props, 1, "off", 7, True)
+    assert base["OUT_IRRADIANCE"].view(np.float32).sum() > 0
+    for pipelines, overlap in SETTINGS[1:]:
+        _same(base, _render(mqlib, props, pipelines, overlap, 7, sync_every_frame), (pipelines, overlap))
+
+
+def test_partitioned_rank_outputs_do_not_depend_on_camera_ray_overlap(mqlib):
+    """"partitioned frames" (the default) switches the overlap on for a rank of a tile partition."""
+    props = {"reference mode": 1, "spp": 1, "max path length": 3}
+    a = _render(mqlib, props, 1, "off", 6, False, partition=(1, 3))
+    b = _render(mqlib, props, 1, "partitioned frames", 6, False, partition=(1, 3))
+    _same(a, b, "rank 1 of 3")
+
+
+def test_guided_frames_from_a_frozen_state_do_not_depend_on_scheduling(mqlib):
+    import mqhip
+    props = {"reference mode": 0, "spp": 1, "max path length": 3}
+    # learn something with the default scheduling, then replay it everywhere
+    ctx = mqhip.Context(0)
+    ctx.header_defaults()
+    ctx.synth_scene("synth_start", 4)
+    for k, v in {"randomize seed": 0, "seed": 0x5EED, **SMALL, **props}.items():
+        ctx.set_property(k, v)
+    ctx.commit(); ctx.connect(328, 200)
+    for f in range(12):
+        ctx.process(ctx.synth_camera(f))
+    learned = (ctx.state_read(0, SMALL["adaptive grid buf size"] + SMALL["static grid buf size"]), ctx.state_read(1, SMALL["LC buf size"]))
+    ctx.close()
+    assert (learned[0]["sum_w"] > 0).sum() > 1000
+    base = _render(mqlib, props, 1, "off", 5, True, learned=learned)
+    assert base["OUT_IRRADIANCE"].view(np.float32).sum() > 0
+    for pipelines, overlap in SETTINGS[1:]:
+        _same(base, _render(mqlib, props, pipelines, overlap, 5, False, learned=learned), (pipelines, overlap))

@@ -1,0 +1,39 @@
+"""Kernel timeline of a few frames (run under `rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/timeline.py`),
+then `python3 tools/timeline.py --read DIR` prints start offsets / durations / queues of the last frames' kernels:
+shows whether launches on different streams really run side by side.
+Environment: MQ_WORLD (tile partition emulated on one GPU, default 8), MQ_PIPELINES, MQ_OVERLAP, MQ_FRAMES (default 40)."""
+import os, sys, glob, csv
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
+
+if len(sys.argv) > 2 and sys.argv[1] == "--read":
+    rows = []
+    for fn in glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True):
+        with open(fn) as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
+    rows.sort()
+    last = int(os.environ.get("MQ_SHOW", "40"))
+    rows = rows[-last:]
+    t0 = rows[0][0]
+    prev_end = t0
+    for s, e, name, q, st in rows:
+        print("%9.1f us  +%7.1f us  gap %6.1f  q%s s%s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, q, st, name))
+        prev_end = max(prev_end, e)
+    sys.exit(0)
+
+import mqhip
+ctx = mqhip.Context(0)
+ctx.json_defaults()
+for k, v in {"randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3}.items():
+    ctx.set_property(k, v)
+if os.environ.get("MQ_PIPELINES"):
+    ctx.set_property("pipelines", int(os.environ["MQ_PIPELINES"]))
+if os.environ.get("MQ_OVERLAP"):
+    ctx.set_property("overlap camera rays", int(os.environ["MQ_OVERLAP"]))
+ctx.synth_scene("synth_sepulcher", 2); ctx.commit()
+ctx.set_partition(0, int(os.environ.get("MQ_WORLD", "8"))); ctx.connect(1920, 1080)
+for f in range(int(os.environ.get("MQ_FRAMES", "40"))):
+    ctx.process(ctx.synth_camera(f))
+ctx.sync()
+ctx.close()
