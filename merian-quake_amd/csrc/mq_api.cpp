@@ -31,7 +31,7 @@ int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, uint32_t sequ
 int mq_launch_debug_view(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_stack_lds_entries();
 int mq_launch_stream_read(const void* src, size_t bytes, uint32_t* sink, int grid, hipStream_t s);
-int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int shade_block, int out[3]);
+int mq_resident_blocks(bool guided, bool merged_trace, size_t shade_lds_bytes, int shade_block, int out[4]);
 int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
 int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s);
@@ -109,7 +109,7 @@ struct mq_ctx {
     MqParams params{};
     bool count_enabled = false;
     int cu_count = 0, grid_blocks = 0;
-    int grid_frame[3] = {0, 0, 0}; // primary, trace, bounce: every block resident (see frame_grids)
+    int grid_frame[4] = {0, 0, 0, 0}; // first hit, trace, bounce, camera rays: every block resident (see frame_grids)
     int grid_key = -1;             // lds_rows2 the grids were derived for
     static const int EV_RING = 32;
     static const int EV_PER = 4 + 2 * 8; // start, primary trace end, primary shade end, (trace end, bounce end) x up to 8 rounds, apply end
@@ -984,18 +984,18 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
 // grid is exactly the number of blocks the chip holds at once (CUs x resident blocks per CU at the
 // kernel's register and LDS footprint): a larger grid runs as a ragged last wave of blocks.
 static int frame_grids(mq_ctx* c, const MqFrame& F) {
-    const int key = (int)F.lds_rows2 * 2 + (c->params.reference_mode ? 1 : 0);
+    const int key = (int)F.lds_rows2 * 4 + (c->params.reference_mode ? 1 : 0) + (c->world > 1 ? 2 : 0);
     if (c->grid_key == key) return MQ_OK;
-    int occ[3] = {0, 0, 0};
-    int e = mq_resident_blocks(!c->params.reference_mode, (size_t)F.lds_rows2 * 64 * 8 * (F.shade_block / 64), (int)F.shade_block, occ);
+    int occ[4] = {0, 0, 0, 0};
+    int e = mq_resident_blocks(!c->params.reference_mode, c->world > 1, (size_t)F.lds_rows2 * 64 * 8 * (F.shade_block / 64), (int)F.shade_block, occ);
     if (e) return fail(c, MQ_EHIP, std::string("occupancy query: ") + hipGetErrorString((hipError_t)e));
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
 #if MQ_GRID_MODE == 0
         c->grid_frame[i] = c->grid_blocks;
 #else
-        c->grid_frame[i] = std::min(i == 1 ? c->grid_blocks : c->grid_blocks * (mq_render_block_size() / (int)F.shade_block), std::max(1, c->cu_count) * std::max(1, occ[i])); // (smaller shading blocks: more of them, the same number of threads at most)
+        c->grid_frame[i] = std::min(i == 1 || i == 3 ? c->grid_blocks : c->grid_blocks * (mq_render_block_size() / (int)F.shade_block), std::max(1, c->cu_count) * std::max(1, occ[i])); // (smaller shading blocks: more of them, the same number of threads at most)
 #endif
-        static const char* const names[3] = {"MQ_DEBUG_PRIMARY_BLOCKS_PER_CU", "MQ_DEBUG_TRACE_BLOCKS_PER_CU", "MQ_DEBUG_BOUNCE_BLOCKS_PER_CU"};
+        static const char* const names[4] = {"MQ_DEBUG_PRIMARY_BLOCKS_PER_CU", "MQ_DEBUG_TRACE_BLOCKS_PER_CU", "MQ_DEBUG_BOUNCE_BLOCKS_PER_CU", "MQ_DEBUG_CAMERA_BLOCKS_PER_CU"};
         if (const char* ev = getenv(names[i])) { int v = atoi(ev); if (v > 0) c->grid_frame[i] = std::min(c->grid_blocks, std::max(1, c->cu_count) * v); } // tuning experiments only
     }
     c->grid_key = key;
@@ -1111,7 +1111,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     const bool packet = c->props.packet_camera_rays && (int)std::max(c->s_depth, c->d_depth) + 2 <= mq_packet_stack_entries();
     if (!c->count_enabled) // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
         for (int k = 0; k < S; k++) {
-            e = mq_launch_primary_trace(c->scene, c->params, FS[k], packet, overlap_pt ? c->grid_frame[1] : sub_grid(1), overlap_pt ? c->pt_stream : st(k));
+            e = mq_launch_primary_trace(c->scene, c->params, FS[k], packet, overlap_pt ? c->grid_frame[3] : sub_grid(3), overlap_pt ? c->pt_stream : st(k));
             if (e) return fail(c, MQ_EHIP, std::string("primary trace launch: ") + hipGetErrorString((hipError_t)e));
         }
     if (overlap_pt) {

@@ -284,11 +284,9 @@ MQ_DEV void trav_defer(const MqSceneDev& sc, Trav& t, uint2* stk) {
     if (sc.dyn_root != MQ_NIL) { stk[0] = make_uint2(sc.dyn_root, 0x80000000u); t.sp = 1; }
 }
 
-// One node visit: pops the nearest pending child, intersects its 8 children; the triangles of the
-// leaves that were hit are left in t.tmask / t.tbase.  Precondition: t.G has a pending child.
-template <bool COUNT>
-MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane] */, unsigned long long* spill, Ctr& ctr) {
-    const bool sx = !(t.oct4 & 1u), sy = !(t.oct4 & 2u), sz = !(t.oct4 & 4u);
+// The two halves of a node visit.  trav_node_pop: the nearest pending child of the current group leaves it (the rest of
+// the group goes to the stack) -- returns the child's record; trav_node_test: its 8 children against the ray.
+MQ_DEV const uint4* trav_node_pop(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane] */, unsigned long long* spill) {
     uint2 G = t.G;
     uint32_t bit = 31u - (uint32_t)__clz((int)G.y);
     G.y &= ~(1u << bit);
@@ -299,9 +297,10 @@ MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane]
     }
     uint32_t slot = (bit - 24u) ^ (t.oct4 & 7u);
     uint32_t rel = (uint32_t)__popc(G.y & 0xffu & ((1u << slot) - 1u));
-    const uint4* np = (const uint4*)(sc.nodes + (G.x + rel));
-    uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-    if (COUNT) ctr.nodes++;
+    return (const uint4*)(sc.nodes + (G.x + rel));
+}
+MQ_DEV void trav_node_test(Trav& t, const uint4 n0, const uint4 n1, const uint4 n2, const uint4 n3, const uint4 n4) {
+    const bool sx = !(t.oct4 & 1u), sy = !(t.oct4 & 2u), sz = !(t.oct4 & 4u);
     const float tlim = t.tlim;
     // 1/d scaled by the node's power-of-two cell size: an exponent-field add (exact; |1/d| is in [1, 1e20] and the
     // biased exponents are far from both ends of the range)
@@ -318,11 +317,18 @@ MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane]
     const uint32_t oct4 = t.oct4;
     uint32_t hm = box4(nx0, ny0, nz0, fx0, fy0, fz0, n1.z, adx, ady, adz, ox, oy, oz, tlim, oct4) |
                   box4(nx1, ny1, nz1, fx1, fy1, fz1, n1.w, adx, ady, adz, ox, oy, oz, tlim, oct4);
-    G.x = n1.x;
-    G.y = (hm & 0xff000000u) | (n0.w >> 24);
-    t.G = G;
+    t.G = make_uint2(n1.x, (hm & 0xff000000u) | (n0.w >> 24));
     t.tmask = hm & 0x00ffffffu;
     t.tbase = n1.y;
+}
+// One node visit: pops the nearest pending child, intersects its 8 children; the triangles of the
+// leaves that were hit are left in t.tmask / t.tbase.  Precondition: t.G has a pending child.
+template <bool COUNT>
+MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane] */, unsigned long long* spill, Ctr& ctr) {
+    const uint4* np = trav_node_pop(sc, t, stk, spill);
+    uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    if (COUNT) ctr.nodes++;
+    trav_node_test(t, n0, n1, n2, n3, n4);
 }
 
 // Tests ONE pending triangle (lowest bit of t.tmask).
@@ -1293,8 +1299,12 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 #ifndef MQ_SHARE
 #define MQ_SHARE 1 // idle lanes adopt subtrees of busy lanes once the queue is exhausted (see the kernel)
 #endif
-template <bool COUNT>
-__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
+// MERGED: the step of the loop visits a node and tests a triangle side by side (one memory latency per step, 106 registers);
+// otherwise the two phases follow each other (two latencies, 80 registers).  A full frame keeps the chip's gather path and
+// its vector ALUs busy whichever way -- the phased loop is 3 % faster there --, a rank of a partitioned frame has few
+// rays per wave and runs at the latency of its longest ray: the merged step is 15 % faster there.  The host picks.
+template <bool COUNT, bool MERGED>
+__global__ __launch_bounds__(MQ_BLOCK, MERGED ? 4 : MQ_OCC_TRACE) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
     const int lane = threadIdx.x & 63;
 #ifdef MQ_PROF
@@ -1317,7 +1327,11 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
     // The wave's pool: `pool_len` entries of shard `pool_s`, starting at entry 64 * pool_j of that shard
     // (a run of MQ_TRACE_BLOCKS 64-entry blocks); `pool_i` entries are already handed out.  All wave-uniform.
     uint32_t pool_s = wave_id & (MQ_SHARDS - 1), pool_j = 0, pool_i = 0, pool_len = 0;
-    const uint32_t per_wave = n_eff / (gridDim.x * MQ_WAVES);
+    // No more waves than 64-ray blocks in the queue (a small queue: late rounds, a rank of a partitioned frame): a wave
+    // that starts with half its lanes empty finishes no earlier and its gathers queue up with everybody else's.
+    const uint32_t n_waves_all = gridDim.x * MQ_WAVES, n_waves = n_eff / 64u < n_waves_all ? (n_eff / 64u > 0u ? n_eff / 64u : 1u) : n_waves_all;
+    if (wave_id >= n_waves) return;
+    const uint32_t per_wave = n_eff / n_waves;
     const uint32_t nblk = per_wave >= 64u * MQ_TRACE_BLOCKS ? MQ_TRACE_BLOCKS : (per_wave >= 128u && MQ_TRACE_BLOCKS >= 2u ? 2u : 1u);
     bool exhausted = false;
     uint32_t q = MQ_NIL; // queue position of the lane's ray; MQ_NIL = the lane is idle
@@ -1431,6 +1445,63 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
         }
         PLAP(ctr, 26);
         if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
+        if (MERGED) {
+        // One step: the triangle test of the leaf found LAST step and the next node visit run side by side -- their
+        // records are requested together (one memory latency per step instead of two) and a lane with a single pending
+        // triangle does both.  The triangle phase is still taken by wave vote (only when enough lanes have triangles
+        // pending, or no lane could do anything else), so the expensive test executes at useful occupancy; the
+        // triangle test comes before the box test, which therefore culls with the closest hit so far.
+        const bool has_tri = busy && t.tmask != 0;
+        const uint32_t ntri = (uint32_t)__popcll(__ballot(has_tri));
+        const uint32_t nwork = (uint32_t)__popcll(__ballot(busy && !fin));
+        const bool do_tri = has_tri && (ntri >= MQ_TRI_VOTE || ntri == nwork);
+        const bool do_node = busy && !fin && t.G.y > 0x00ffffffu && (t.tmask == 0 || (do_tri && (t.tmask & (t.tmask - 1u)) == 0u));
+#ifdef MQ_PROF
+        { const uint32_t nn = (uint32_t)__popcll(__ballot(do_node)), nb = (uint32_t)__popcll(__ballot(busy)), nt = (uint32_t)__popcll(__ballot(do_tri));
+          if (nn) { ctr.prof[12]++; ctr.prof[13] += nn; } if (nt) { ctr.prof[14]++; ctr.prof[15] += nt; } ctr.prof[11]++; ctr.prof[30] += nb;
+          if (exhausted && pool_i == pool_len) { ctr.prof[22]++; ctr.prof[23] += nb; } }
+#endif
+        // Both records are requested by EVERY lane, in straight-line code (a lane without a triangle / node to visit asks
+        // for record 0: one shared line, nearly free): the number of loads in flight is then the same on every path, so
+        // the triangle test waits for the triangle only and runs under the latency of the node record.  (Requests
+        // inside the divergent branches make the compiler wait for everything at the join.)
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        uint32_t tri_id = 0;
+        if (do_tri) {
+            const uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
+            t.tmask &= t.tmask - 1u;
+            tri_id = t.tbase + k;
+            if (COUNT) ctr.tris++;
+        }
+        const uint4* np = (const uint4*)sc.nodes;
+        if (do_node) {
+            np = trav_node_pop(sc, t, stk, spill);
+            if (COUNT) ctr.nodes++;
+        }
+        const u4v* tp = (const u4v*)(sc.tris + tri_id);
+        u4v ta = tp[0], tb = tp[1], tc = tp[2];
+        __builtin_amdgcn_sched_barrier(0); // the triangle first: loads return in order
+        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+        PLAP(ctr, 27);
+        if (do_tri) {
+            float tt = 0.0f, u = 0.0f, v = 0.0f;
+            bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(ta.x), __uint_as_float(ta.y), __uint_as_float(ta.z)),
+                                    F3(__uint_as_float(ta.w), __uint_as_float(tb.x), __uint_as_float(tb.y)),
+                                    F3(__uint_as_float(tb.z), __uint_as_float(tb.w), __uint_as_float(tc.x)), tt, u, v);
+            accept = accept && (tt < MQ_T_MAX) && (tt < t.hit.t || (tt == t.hit.t && tc.y < t.best_key));
+            if (accept && (tc.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, tri_id, u, v);
+            if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = tri_id; t.best_key = tc.y; t.tlim = trav_limit(tt); }
+        }
+        if (do_node) {
+            trav_node_test(t, n0, n1, n2, n3, n4);
+            (void)trav_next(t, stk, spill); // group exhausted: the next one comes off the stack now
+        }
+        PLAP(ctr, 28);
+#ifdef MQ_PROF
+        if (busy) ray_iters++;
+#endif
+        if (busy && !fin) fin = !(t.G.y > 0x00ffffffu) && t.tmask == 0;
+        } else {
         // node phase: lanes without pending triangles visit one node
         const bool want_node = busy && !fin && t.tmask == 0;
 #ifdef MQ_PROF
@@ -1456,6 +1527,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_trace_queue_kernel(
         if (busy) ray_iters++;
 #endif
         if (busy && !fin && t.tmask == 0) fin = trav_next(t, stk, spill);
+        }
         if (SHARE) { // finished helpers hand their closest hit to the owner lane, one at a time (wave-uniform loop)
             unsigned long long hm = __ballot(busy && fin && owner >= 0);
             while (hm) {
@@ -2150,7 +2222,10 @@ int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFra
 }
 int mq_packet_stack_entries() { return MQ_PKT_STACK; }
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s) {
-    if (count) mq_trace_queue_kernel<true><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round); else mq_trace_queue_kernel<false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
+    const bool merged = F.world > 1u; // a rank of a partitioned frame: see the kernel
+    if (count) mq_trace_queue_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
+    else if (merged) mq_trace_queue_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
+    else mq_trace_queue_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
     return (int)hipGetLastError();
 }
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s) {
@@ -2226,17 +2301,20 @@ int mq_render_block_size() { return MQ_BLOCK; }
 int mq_spill_entries() { return MQ_SPILL_ENTRIES; }
 int mq_stack_lds_entries() { return MQ_STACK_LDS; }
 // resident blocks per CU of the three frame kernels at the given dynamic LDS size: {primary, trace, bounce}
-int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int shade_block, int out[3]) {
-    int a = 0, b = 0, c = 0;
+int mq_resident_blocks(bool guided, bool merged_trace, size_t shade_lds_bytes, int shade_block, int out[4]) {
+    int a = 0, b = 0, c = 0, d = 0;
     hipError_t e;
     if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<true, false>, shade_block, shade_lds_bytes);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<false, false>, shade_block, shade_lds_bytes);
     if (e != hipSuccess) return (int)e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false>, MQ_BLOCK, 0);
+    if (merged_trace) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false, true>, MQ_BLOCK, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false, false>, MQ_BLOCK, 0);
+    if (e != hipSuccess) return (int)e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, mq_primary_trace_lanes_kernel, MQ_BLOCK, 0);
     if (e != hipSuccess) return (int)e;
     if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<true, false>, shade_block, shade_lds_bytes);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, mq_bounce_kernel<false, false>, shade_block, 0);
     if (e != hipSuccess) return (int)e;
-    out[0] = a; out[1] = b; out[2] = c;
+    out[0] = a; out[1] = b; out[2] = c; out[3] = d; // first hit, trace, bounce, camera rays
     return 0;
 }

@@ -27,12 +27,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="synth_sepulcher"); ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--world", type=int, default=1, help="profile rank 0 of a tile partition of this many ranks")
     a = ap.parse_args()
     ctx = mqhip.Context(0)
     ctx.json_defaults()
     for k, v in {"randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3, "reference mode": 0, "volume spp": 0}.items():
         ctx.set_property(k, v)
-    ctx.synth_scene(a.scene, 2); ctx.commit(); ctx.connect(a.width, a.height)
+    ctx.synth_scene(a.scene, 2); ctx.commit(); ctx.set_partition(0, a.world); ctx.connect(a.width, a.height)
     for f in range(10):
         ctx.process(ctx.synth_camera(f))
     ctx.section_clocks(reset=True)
