@@ -1290,6 +1290,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 // most 64-entry blocks fetched per refill.  One block: with 256-ray refills the ~7400 chunks of a 1080p
 // round spread over 6144 resident waves as "one or two each", i.e. a 2x makespan imbalance (measured:
 // 44 of 64 lanes busy on average, trace rounds 0.474 + 0.225 ms against 0.448 + 0.211 ms with 64-ray refills).
+#ifndef MQ_REFILL_MIN
+#define MQ_REFILL_MIN 8u
+#endif
 #ifndef MQ_TRI_VOTE
 #define MQ_TRI_VOTE 16u
 #endif
@@ -1303,8 +1306,11 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 // otherwise the two phases follow each other (two latencies, 80 registers).  A full frame keeps the chip's gather path and
 // its vector ALUs busy whichever way -- the phased loop is 3 % faster there --, a rank of a partitioned frame has few
 // rays per wave and runs at the latency of its longest ray: the merged step is 15 % faster there.  The host picks.
-template <bool COUNT, bool MERGED>
-__global__ __launch_bounds__(MQ_BLOCK, MERGED ? 4 : MQ_OCC_TRACE) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
+#ifndef MQ_OCC_TRACEQ
+#define MQ_OCC_TRACEQ MQ_OCC_TRACE
+#endif
+template <bool MERGED, bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK, MERGED ? 4 : MQ_OCC_TRACEQ) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
     const int lane = threadIdx.x & 63;
 #ifdef MQ_PROF
@@ -1362,7 +1368,9 @@ __global__ __launch_bounds__(MQ_BLOCK, MERGED ? 4 : MQ_OCC_TRACE) void mq_trace_
     for (;;) {
         unsigned long long idle = __ballot(!busy);
         PLAP(ctr, 24);
-        if (idle) {
+        // Refill in batches: fetching rays (a round trip to memory, three divisions per ray) costs the whole wave the same
+        // for one idle lane as for sixteen, and a few lanes finish in every step.
+        if ((uint32_t)__popcll(idle) >= (exhausted ? 1u : MQ_REFILL_MIN)) {
             while (pool_i == pool_len && !exhausted) { // refill: next run of blocks of the current shard
                 uint32_t cnt = 0, head = 0;
                 if (lane == 0) { cnt = tails[pool_s * MQ_SHARD_STRIDE]; head = __hip_atomic_load(&heads[pool_s * MQ_SHARD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2223,8 +2231,8 @@ int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFra
 int mq_packet_stack_entries() { return MQ_PKT_STACK; }
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s) {
     const bool merged = F.world > 1u; // a rank of a partitioned frame: see the kernel
-    if (count) mq_trace_queue_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
-    else if (merged) mq_trace_queue_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
+    if (count) mq_trace_queue_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
+    else if (merged) mq_trace_queue_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
     else mq_trace_queue_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
     return (int)hipGetLastError();
 }
@@ -2307,7 +2315,7 @@ int mq_resident_blocks(bool guided, bool merged_trace, size_t shade_lds_bytes, i
     if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<true, false>, shade_block, shade_lds_bytes);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<false, false>, shade_block, shade_lds_bytes);
     if (e != hipSuccess) return (int)e;
-    if (merged_trace) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false, true>, MQ_BLOCK, 0);
+    if (merged_trace) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<true, false>, MQ_BLOCK, 0);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false, false>, MQ_BLOCK, 0);
     if (e != hipSuccess) return (int)e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, mq_primary_trace_lanes_kernel, MQ_BLOCK, 0);

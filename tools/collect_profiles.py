@@ -8,6 +8,8 @@
   profiles/<tag>_timed_region.json         from the kernel trace of the same run: mean duration per kernel over the launches
                                            of the TIMED frames only (the --stats summary above also averages the
                                            lighter warm-up frames), next to the hipEvent figures of the bench line
+  profiles/<tag>_unit_busy.json            per kernel: busy share of the texture address (TA) and data (TD) units and of vector-ALU
+                                           issue, = counter / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs), from three counter-only passes
   profiles/<tag>_bench_under_rocprof.json  the bench line of the traced run
   profiles/<tag>_bench.json                the bench line of an unprofiled run on the same box"""
 import glob, json, os, shutil, sys
@@ -83,6 +85,22 @@ def main(tag):
         ev = bench["roofline"]
         out["bench_hipevent_ms_per_launch"] = {ev["kernel"]: ev["kernel_ms_per_launch"]}
         json.dump(out, open(os.path.join(dst, tag + "_timed_region.json"), "w"), indent=1)
+    # unit-busy shares: every pass carries its own GRBM_GUI_ACTIVE (summed over the 8 XCDs); one TA / TD / SQ per CU
+    busy = {}
+    for d, names in (("unit_ta", {"TA_TA_BUSY_sum": "ta_busy"}), ("unit_td", {"TD_TD_BUSY_sum": "td_busy", "TD_TC_STALL_sum": "td_stalled_by_tc"}),
+                     ("unit_sq", {"SQ_ACTIVE_INST_VALU": "valu_active", "SQ_ACTIVE_INST_SCA": "scalar_active", "SQ_ACTIVE_INST_LDS": "lds_active", "SQ_ACTIVE_INST_ANY": "any_active"})):
+        for kn, v in summarise(os.path.join(src, d)).items():
+            if not kn.startswith("mq_") or "GRBM_GUI_ACTIVE" not in v or "true>" in kn.split(",")[-1]:
+                continue
+            cu_cycles = v["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 256.0
+            for c, name in names.items():
+                if c in v:
+                    busy.setdefault(kn, {})[name] = round(v[c]["mean"] / cu_cycles, 4)
+            busy[kn]["launches"] = v["GRBM_GUI_ACTIVE"]["launches"]
+    if busy:
+        busy["_run"] = {"command": "python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 (tools/profile_round.sh, three counter-only passes)",
+                        "definition": "counter / (GRBM_GUI_ACTIVE / 8 * 256): share of CU-cycles the unit was busy, mean over all launches of the run"}
+        json.dump(busy, open(os.path.join(dst, tag + "_unit_busy.json"), "w"), indent=1)
     print("profiles written for", tag)
 
 if __name__ == "__main__":
