@@ -99,13 +99,17 @@ def cpu_baseline(ctx, scene, seed, props, W, H, warm, timed):
             "sample": "%dx%d (same scene, camera, parameters), %d warm-up + %d timed guided frames, plain binary BVH, %d pthreads" % (W, H, warm, timed, cores)}
 
 
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks of this script (one process per
     GPU) with torch.distributed.run BEFORE this process has touched the GPU, relay rank 0's JSON line, fail if a rank
     fails.  Nothing is re-exec'd: the ranks are fresh child processes."""
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
@@ -162,6 +166,11 @@ def main():
     rehearsal = os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") in ("1", "2")  # "2": rehearse the overlapped exchange too
     if rehearsal:
         local_rank = 0
+    # Second rehearsal switch (tests only): the REAL exchange path -- RCCL process group, all_gather_into_tensor on the side
+    # stream, un-tiling -- with a world of ONE rank, which is all a one-GPU box can give RCCL (it refuses two ranks on one
+    # device).  The frame is not partitioned; the assembled image must equal the rendered one.
+    selftest = world == 1 and os.environ.get("MQ_BENCH_RCCL_SELFTEST") == "1"
+    exchange = world > 1 or selftest
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -171,6 +180,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus, "the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
+    elif selftest:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     if not torch.cuda.is_available():
@@ -204,8 +218,8 @@ def main():
     # The exchange of frame N overlaps the rendering of frame N + 1: tiles are copied to a staging buffer on the
     # render stream, the RCCL all-gather and the un-tiling into a bench-owned image run on a side stream.
     # MQ_BENCH_SYNC_EXCHANGE=1 keeps everything on the render stream (and un-tiles into MQ_OUT_IRRADIANCE).
-    overlap = world > 1 and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1" and (not rehearsal or os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") == "2")
-    if world > 1:
+    overlap = exchange and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1" and (not rehearsal or os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") == "2")
+    if exchange:
         local = torch.as_tensor(_DevArray(tiles_ptr, tile_bytes // 4), device="cuda")
         gathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
         if args.volume_spp > 0:  # configs with volumes exchange the "volume" image too
@@ -232,7 +246,7 @@ def main():
 
     def step(frame):
         ctx.process(ctx.synth_camera(frame), True, stream)
-        if world == 1:
+        if not exchange:
             return
         if not overlap:
             gather_sync(gathered, local, ctx.untile)
@@ -259,7 +273,7 @@ def main():
                 ctx.untile_to(dst.data_ptr(), img.data_ptr(), side.cuda_stream)
 
     def sync_all():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -277,7 +291,7 @@ def main():
         step(frame); frame += 1
     sync_all()
     dt = time.perf_counter() - t0
-    if overlap and rehearsal:  # rehearsal only: the assembled image must contain this rank's tiles of the last frame
+    if overlap and (rehearsal or selftest):  # rehearsals only: the assembled image must contain this rank's tiles of the last frame
         import mq_tiles
         got = mq_tiles.tile_image(image.cpu().numpy().reshape(H, W, 4), rank, world)
         assert np.array_equal(got, local.cpu().numpy().reshape(-1, 64, 4)), "overlapped exchange lost tiles"
@@ -289,7 +303,7 @@ def main():
     per_round = ctx.timing_rounds()
     n_detail = ctx.timing_detail_frames()
     ctx.timing_set_interval(1)
-    if world > 1:
+    if exchange:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -329,7 +343,7 @@ def main():
     dom_bytes_per_launch = kbytes[dom] / launches[dom]
     achieved = dom_bytes_per_launch / (dom_ms_per_launch * 1e-3) / 1e9
     pipeline_ms = render_sum / n_timed
-    default_workload = (world == 1 and (W, H) == (1920, 1080) and args.scene == "synth_sepulcher" and args.scene_seed == 2
+    default_workload = (world == 1 and not selftest and (W, H) == (1920, 1080) and args.scene == "synth_sepulcher" and args.scene_seed == 2
                         and args.spp == 1 and not args.reference_mode and args.volume_spp == 0)
     traffic, traffic_src = pmc_traffic(dom, default_workload, learn, args.steps)
     # `achieved` / `frac`: ALGORITHMIC bytes of the dominant kernel per launch over its measured launch time (the contract's
@@ -355,14 +369,14 @@ def main():
            "config": {"workload": "%s, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
                                   % ("user-supplied map %s, camera at the player start" % args.scene if bsp else "%s(seed=%d) stand-in for ad_sepulcher" % (args.scene, args.scene_seed),
                                      W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
-                      "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world, "ranks": world, "backend": (dist.get_backend() if world > 1 else "none"),
-                      "collective": "none" if world == 1 else "%dx RCCL all_gather of %d B/rank per frame%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "")},
+                      "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world, "ranks": world, "backend": (dist.get_backend() if exchange else "none"),
+                      "collective": "none" if not exchange else "%dx RCCL all_gather of %d B/rank per frame%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "")},
            "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, args.scene, args.scene_seed, props, W, H, 3, 8)  # the headline frame size: ~25 s of host time
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

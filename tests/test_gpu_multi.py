@@ -115,3 +115,18 @@ def test_timing_interval_and_images_do_not_depend_on_it(mqlib):
         imgs.append(ctx.irradiance().copy())
         ctx.close()
     assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+
+
+def test_bench_exchange_path_on_real_rccl_with_one_rank(mqlib):
+    """`MQ_BENCH_RCCL_SELFTEST=1`: bench.py's exchange code (RCCL process group, all_gather_into_tensor of the tile buffer on
+    the side stream overlapped with the next frame, device un-tiling, the MAX all-reduce of the time) with the largest world
+    a one-GPU box can give RCCL: one rank.  bench.py itself asserts that the assembled image equals the rendered tiles."""
+    import json
+    import subprocess
+    env = dict(os.environ, MQ_BENCH_RCCL_SELFTEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                        "--width", "640", "--height", "360", "--scene", "synth_start", "--scene-seed", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl" and "all_gather" in line["config"]["collective"]
+    assert line["value"] > 0
