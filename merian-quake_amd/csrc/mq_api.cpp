@@ -469,8 +469,10 @@ int mq_create(mq_ctx** out, int device) {
         { // its own hardware queue: streams of one priority share a small pool of queues round robin (this one landed on the
           // caller's queue and its launches ran in line with the frame); a lower priority has its own pool, and fill-in work is what it is
             int least = 0, greatest = 0;
-            ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-            ok = ok && hipStreamCreateWithPriority(&c->pt_stream, hipStreamNonBlocking, least) == hipSuccess;
+            if (ok && (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->pt_stream, hipStreamNonBlocking, least) != hipSuccess)) {
+                (void)hipGetLastError(); // no priorities on this device: an ordinary stream (the overlap may then not happen, the results are the same)
+                ok = hipStreamCreateWithFlags(&c->pt_stream, hipStreamNonBlocking) == hipSuccess;
+            }
         }
         for (int k = 0; ok && k < 2; k++) ok = hipEventCreateWithFlags(&c->ev_pt_done[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_shaded[k], hipEventDisableTiming) == hipSuccess;
         for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) ok = ok && hipEventCreate(&e4) == hipSuccess;

@@ -588,8 +588,19 @@ MQ_DEV float lc_inv_width(const MqParams& P, uint32_t level) {
 }
 MQ_DEV f3 cam_pos(const mq_uniform& U) { return F3(U.cam_x[0], U.cam_x[1], U.cam_x[2]); }
 
+// the level of the adaptive grid at `pos` before the jitter (mc.glsl:62-68): a square root, two logarithms and two
+// divisions that depend on the position only -- the K lookups of one path vertex compute it once
+MQ_DEV uint32_t mc_adaptive_base_level(const MqParams& P, const mq_uniform& U, f3 pos) {
+    return grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, cam_pos(U), pos);
+}
+MQ_DEV void mc_adaptive_buffer_index_at(const MqParams& P, uint32_t base_level, uint32_t& rng, f3 pos, f3 normal, uint32_t& index, uint32_t& hash16) {
+    uint32_t level = base_level + level_jitter(xorshift(rng)); // mc.glsl:70
+    i3 g = grid_idx_interpolate(pos, mc_inv_width(P, level), xorshift(rng));
+    index = hash_grid_normal_level(g, normal, level, P.mc_adaptive_buffer_size);
+    hash16 = hash2_grid_level(g, level) & 0xffffu;
+}
 MQ_DEV void mc_adaptive_buffer_index(const MqParams& P, const mq_uniform& U, uint32_t& rng, f3 pos, f3 normal, uint32_t& index, uint32_t& hash16) {
-    uint32_t level = grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, cam_pos(U), pos);
+    uint32_t level = mc_adaptive_base_level(P, U, pos);
     level += level_jitter(xorshift(rng)); // mc.glsl:70
     i3 g = grid_idx_interpolate(pos, mc_inv_width(P, level), xorshift(rng));
     index = hash_grid_normal_level(g, normal, level, P.mc_adaptive_buffer_size);
@@ -875,6 +886,7 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                 // lobes[(6 * i + c) * 64] so that K may be a run-time value without indexed VGPRs.
                 // The 48-byte state of lookup i + 1 is requested before state i is processed.
                 const f3 lp = p.smp == 0 ? p.cur.prev_pos : p.cur.pos;
+                const uint32_t base_level = K > 0 ? mc_adaptive_base_level(P, U, lp) : 0u;
                 p.score_sum = 0.0f; p.mc_index = MQ_NIL; p.mc_id = 0; p.mc_sum_w = 0.0f;
                 MCS sel = {};
                 uint32_t bi_next = 0, h16_next = 0; bool adapt_next = false; float xsel_next = 0.0f;
@@ -885,7 +897,7 @@ MQ_DEV bool advance_path(const MqParams& P, const MqFrame& F, Path& p, uint32_t 
                     const uint32_t bi = bi_next, h16 = h16_next; const bool adapt = adapt_next; const float xsel = xsel_next;
                     if (i + 1 < K) { // RNG draws stay in stream order: [grid, level, cell | cell, select] per lookup
                         adapt_next = xorshift(p.rng) < P.mc_samples_adaptive_prob;
-                        if (adapt_next) mc_adaptive_buffer_index(P, U, p.rng, lp, p.cur.normal, bi_next, h16_next);
+                        if (adapt_next) mc_adaptive_buffer_index_at(P, base_level, p.rng, lp, p.cur.normal, bi_next, h16_next);
                         else mc_static_buffer_index(P, p.rng, lp, bi_next, h16_next);
                         xsel_next = xorshift(p.rng);
                         st_next = mc_load(F.mc, bi_next);
@@ -1809,11 +1821,12 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kerne
                     const f3 nrm = -first_wi;
                     float wo_p = 0.0f, score_sum = 0.0f;
                     MCS sel = {}; uint32_t mc_index = MQ_NIL;
+                    const uint32_t base_level = K > 0 ? mc_adaptive_base_level(P, U, cur_pos) : 0u;
 #pragma nounroll
                     for (int i = 0; i < K; i++) {
                         const bool adapt = xorshift(v.rng) < P.mc_samples_adaptive_prob;
                         uint32_t bi, h16;
-                        if (adapt) mc_adaptive_buffer_index(P, U, v.rng, cur_pos, nrm, bi, h16);
+                        if (adapt) mc_adaptive_buffer_index_at(P, base_level, v.rng, cur_pos, nrm, bi, h16);
                         else mc_static_buffer_index(P, v.rng, cur_pos, bi, h16);
                         MCS st = mc_load(F.mc, bi);
                         if (COUNT) ctr.mc_reads++;
