@@ -388,6 +388,8 @@ void props_to_params(mq_ctx* c) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
         P.lc_inv_width_lut[l] = 1.0f / grid_width(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_min_width, P.lc_grid_power, l);
     }
+    P.mc_log_power = mq_log(P.mc_adaptive_grid_power); P.mc_inv_power = 1.0f / P.mc_adaptive_grid_power;
+    P.lc_log_power = mq_log(P.lc_grid_power); P.lc_inv_power = 1.0f / P.lc_grid_power;
     c->params_dirty = false;
 }
 

@@ -571,11 +571,12 @@ MQ_DEV void shade_hit(const MqSceneDev& sc, const MqParams& P, const mq_uniform&
 // ------------------------------------------------------------------------------------------------
 // hash-grid addressing (mc.glsl:62-88,117-121; light_cache.glsl:13-29)
 // ------------------------------------------------------------------------------------------------
-MQ_DEV uint32_t grid_level(int type, float steps, float tan_half, float minw, float power, f3 cam, f3 pos) {
+// log_power = mq_log(power), inv_power = 1 / power: from the host (MqParams), the same floats the expressions give here
+MQ_DEV uint32_t grid_level(int type, float steps, float tan_half, float minw, float log_power, float inv_power, f3 cam, f3 pos) {
     float w = 2.0f * tan_half * length(cam - pos);
     float lv;
-    if (type == 0) lv = steps * mq_log(mmax(w, minw) / minw) / mq_log(power);
-    else lv = steps * mq_pow(mmax(w - minw, 0.0f), 1.0f / power);
+    if (type == 0) lv = steps * mq_log(mmax(w, minw) / minw) / log_power;
+    else lv = steps * mq_pow(mmax(w - minw, 0.0f), inv_power);
     return (uint32_t)floorf(lv + 0.5f);
 }
 MQ_DEV float mc_inv_width(const MqParams& P, uint32_t level) {
@@ -591,7 +592,7 @@ MQ_DEV f3 cam_pos(const mq_uniform& U) { return F3(U.cam_x[0], U.cam_x[1], U.cam
 // the level of the adaptive grid at `pos` before the jitter (mc.glsl:62-68): a square root, two logarithms and two
 // divisions that depend on the position only -- the K lookups of one path vertex compute it once
 MQ_DEV uint32_t mc_adaptive_base_level(const MqParams& P, const mq_uniform& U, f3 pos) {
-    return grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, cam_pos(U), pos);
+    return grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_log_power, P.mc_inv_power, cam_pos(U), pos);
 }
 MQ_DEV void mc_adaptive_buffer_index_at(const MqParams& P, uint32_t base_level, uint32_t& rng, f3 pos, f3 normal, uint32_t& index, uint32_t& hash16) {
     uint32_t level = base_level + level_jitter(xorshift(rng)); // mc.glsl:70
@@ -683,7 +684,7 @@ MQ_DEV void light_cache_get_level(const MqParams& P, const MqLCCell* lc, uint32_
     else { irr = F3(0.0f, 0.0f, 0.0f); N = 0; }
 }
 MQ_DEV uint32_t lc_level(const MqParams& P, const mq_uniform& U, f3 pos) {
-    return grid_level(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_tan_alpha_half, P.lc_grid_min_width, P.lc_grid_power, cam_pos(U), pos);
+    return grid_level(P.lc_grid_type, P.lc_grid_steps_per_unit_size, P.lc_grid_tan_alpha_half, P.lc_grid_min_width, P.lc_log_power, P.lc_inv_power, cam_pos(U), pos);
 }
 MQ_DEV f3 light_cache_get(const MqParams& P, const mq_uniform& U, const MqLCCell* lc, uint32_t& rng, f3 pos, f3 normal) {
     f3 irr; uint32_t N;
@@ -2124,7 +2125,7 @@ __global__ void mq_debug_view_kernel(MqParams P, MqFrame F) {
         case 1: out = F3(st.sum_w * 0.1f, st.sum_w * 0.1f, st.sum_w * 0.1f); break;
         case 2: { f3 d = mc_state_dir(st, h.pos); out = F3((d.x + 1.0f) / 2.0f, (d.y + 1.0f) / 2.0f, (d.z + 1.0f) / 2.0f); break; }
         case 3: {
-            uint32_t level = grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, cam_pos(U), h.pos);
+            uint32_t level = grid_level(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_tan_alpha_half, P.mc_adaptive_grid_min_width, P.mc_log_power, P.mc_inv_power, cam_pos(U), h.pos);
             i3 g = grid_idx_interpolate(h.pos, mc_inv_width(P, level), 0.5f);
             uint32_t seed = hash2_grid(g);
             float x0 = xorshift(seed), x1 = xorshift(seed);

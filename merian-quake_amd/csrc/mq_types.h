@@ -153,6 +153,9 @@ struct MqParams {
     float mc_static_inv_width;
     float mc_inv_width_lut[MQ_WIDTH_LUT]; // 1 / width(level) of the adaptive MC grid
     float lc_inv_width_lut[MQ_WIDTH_LUT]; // 1 / width(level) of the light-cache grid
+    // constants of grid_level() that depend on the parameters only, evaluated on the host with the kernels' own float
+    // code (mq_log, IEEE division): log(power) and 1 / power of the adaptive MC grid and of the light-cache grid
+    float mc_log_power, mc_inv_power, lc_log_power, lc_inv_power;
 };
 
 struct MqGeoDev {
