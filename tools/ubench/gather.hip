@@ -75,6 +75,10 @@ int main() {
             run<3, 3>(tab, n48, occ, 64, out, "48-B record, 3 x dwordx4");
             run<4, 4>(tab, n80, occ, 64, out, "64-B record, 4 x dwordx4");
             run<1, 5>(tab, n80, occ, 64, out, "80-B stride, 1 x dwordx4");
+            run<5, 8>(tab, (uint32_t)(mb * 1000000 / 128), occ, 64, out, "80-B record at 128-B stride");
+            run<5, 8>(tab, (uint32_t)(mb * 1000000 / 128), occ, 32, out, "80-B record at 128-B stride");
+            run<3, 4>(tab, (uint32_t)(mb * 1000000 / 64), occ, 64, out, "48-B record at 64-B stride");
+            run<4, 4>(tab, (uint32_t)(mb * 1000000 / 64), occ, 64, out, "64-B record at 64-B stride");
             run<5, 5, 64>(tab, n80, occ, 64, out, "80-B rec, wave-shared, vector");
             run<5, 5, 8>(tab, n80, occ, 64, out, "80-B rec, 8 lanes share");
             run<5, 5, 64, true>(tab, n80, occ, 64, out, "80-B rec, wave-shared, scalar");
