@@ -16,6 +16,7 @@
 #include <cstring>
 #include <future>
 #include <queue>
+#include <deque>
 
 namespace {
 
@@ -146,14 +147,19 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
     // ---- collapse to 8-wide ---------------------------------------------------------------------
     struct Work { int bnode; uint32_t out_index; uint32_t depth; };
     uint32_t max_depth = 0;
-    std::queue<Work> q;
+    // Order in which nodes are expanded = order of their child blocks (and of their triangles and shading records) in
+    // memory.  Depth first: a subtree's blocks are neighbours, so a ray walking down finds its next nodes in lines it
+    // has just touched (-0.5 % frame time against breadth first, MQ_BVH_ORDER=bfs, which spreads a path over the levels).
+    std::deque<Work> q;
+    static const bool dfs_order = !(getenv("MQ_BVH_ORDER") && !strcmp(getenv("MQ_BVH_ORDER"), "bfs"));
     out_nodes.emplace_back();
-    q.push({root, 0, 1});
+    q.push_back({root, 0, 1});
     out_tris.reserve(n);
     double sah = 0.0;
     const float root_area = std::max(B.nodes[root].box.area(), 1e-30f);
     while (!q.empty()) {
-        Work w = q.front(); q.pop();
+        Work w;
+        if (dfs_order) { w = q.back(); q.pop_back(); } else { w = q.front(); q.pop_front(); }
         max_depth = std::max(max_depth, w.depth);
         // gather up to 8 children: repeatedly open the internal child with the largest area
         int ch[8]; int nc = 0;
@@ -232,7 +238,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
             if (cn.count == 0) {
                 node.imask |= (uint8_t)(1u << s);
                 node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
-                q.push({c, next_child++, w.depth + 1});
+                q.push_back({c, next_child++, w.depth + 1});
                 sah += (double)cn.box.area() / root_area;
             } else {
                 uint32_t unary = cn.count == 1 ? 1u : (cn.count == 2 ? 3u : 7u);
