@@ -85,7 +85,9 @@ std::vector<std::map<std::string, std::string>> parse_entities(const char* s, si
         if (i >= n) return false;
         if (s[i] == '"') { i++; while (i < n && s[i] != '"') t.push_back(s[i++]); if (i < n) i++; return true; }
         if (s[i] == '{' || s[i] == '}') { t.push_back(s[i++]); return true; }
-        while (i < n && s[i] > ' ' && s[i] != '{' && s[i] != '}') t.push_back(s[i++]);
+        const size_t start = i;
+        while (i < n && (unsigned char)s[i] > ' ' && s[i] != '{' && s[i] != '}') t.push_back(s[i++]);
+        if (i == start) i++; // a control byte outside a quoted string (damaged lump): skip it, always advance
         return true;
     };
     std::string t;
@@ -207,9 +209,11 @@ bool mq_bsp_load(mq_ctx* ctx, const char* bsp_path, const char* palette_path, st
         }
     }
     // ---- geometry ------------------------------------------------------------------------------
-    const float* verts = (const float*)lump_ptr(3); size_t nverts = (size_t)lumps[3].len / 12;
-    const TexInfo* texinfo = (const TexInfo*)lump_ptr(6); size_t ntexinfo = (size_t)lumps[6].len / sizeof(TexInfo);
-    const int32_t* surfedges = (const int32_t*)lump_ptr(13); size_t nsurfedges = (size_t)lumps[13].len / 4;
+    // typed lumps are copied out: a lump may start at any byte offset of the file
+    const size_t nverts = (size_t)lumps[3].len / 12, ntexinfo = (size_t)lumps[6].len / sizeof(TexInfo), nsurfedges = (size_t)lumps[13].len / 4;
+    std::vector<float> verts_v(3 * nverts + 1); std::vector<TexInfo> texinfo_v(ntexinfo + 1); std::vector<int32_t> surfedges_v(nsurfedges + 1);
+    memcpy(verts_v.data(), lump_ptr(3), 12 * nverts); memcpy((void*)texinfo_v.data(), lump_ptr(6), sizeof(TexInfo) * ntexinfo); memcpy(surfedges_v.data(), lump_ptr(13), 4 * nsurfedges);
+    const float* verts = verts_v.data(); const TexInfo* texinfo = texinfo_v.data(); const int32_t* surfedges = surfedges_v.data();
     size_t edge_sz = bsp2 ? 8 : 4, nedges = (size_t)lumps[12].len / edge_sz;
     size_t face_sz = bsp2 ? 28 : 20, nfaces = (size_t)lumps[7].len / face_sz;
     if ((size_t)lumps[14].len < sizeof(Model)) { err = "no models"; return false; }

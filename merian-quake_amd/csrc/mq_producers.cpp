@@ -379,7 +379,7 @@ int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_
             if (!rd(f, at, fh) || fh.width < 1 || fh.height < 1 || at + (size_t)fh.width * fh.height > f.size()) return mq_ctx_fail(ctx, MQ_EIO, "truncated sprite frame");
             if (k == 0) {
                 if (next_tex + 1 >= MQ_MAX_GLTEXTURES) return mq_ctx_fail(ctx, MQ_EINVAL, "too many textures");
-                MqSpriteFrame sf; sf.up = (float)fh.origin[1]; sf.down = (float)(fh.origin[1] - fh.height); sf.left = (float)fh.origin[0]; sf.right = (float)(fh.width + fh.origin[0]);
+                MqSpriteFrame sf; sf.up = (float)fh.origin[1]; sf.down = (float)((int64_t)fh.origin[1] - fh.height); sf.left = (float)fh.origin[0]; sf.right = (float)((int64_t)fh.width + fh.origin[0]); // (64-bit: the origin of a damaged file may be anything)
                 sf.smax = 1.0f; sf.tmax = 1.0f; sf.texnum = next_tex++; sf.alpha = true; // index 255 is transparent: TEXPREF_ALPHA
                 upload_indexed(ctx, f.data() + at, (uint32_t)fh.width, (uint32_t)fh.height, pal, true, sf.texnum, nullptr, &next_tex);
                 m.frames.push_back(sf);
