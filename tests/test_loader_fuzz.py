@@ -87,3 +87,28 @@ def test_damaged_maps_and_texture_files_are_refused_not_crashed_on(mq, tmp_path,
         open(pal, "wb").write(bytes(rng.integers(0, 256, size, dtype=np.uint8)))
         _try(mq, lambda: ctx.load_bsp(good, pal))
     ctx.close()
+
+
+def test_damaged_graph_files_are_refused_not_crashed_on(mq):
+    """mq_load_properties_json has its own small JSON reader (graph files are user-edited)."""
+    import json
+    from test_host_logic import REFERENCE_JSON
+    rng = np.random.default_rng(5)
+    text = json.dumps(REFERENCE_JSON, indent=1).encode()
+    ctx = mq.Context(-1)
+    assert ctx.load_properties_json(text.decode(), "render_markovchain") >= 0
+    specials = [b'"', b"\\", b"{", b"}", b"[", b"]", b":", b",", b"\x00", b"\xff", b"e", b"-", b"1e999", b"\\u12", b"nul", b"tru"]
+    for _ in range(600):
+        b = bytearray(text)
+        for _k in range(int(rng.integers(1, 5))):
+            at = int(rng.integers(0, len(b)))
+            if rng.random() < 0.5:
+                b[at:at + 1] = specials[int(rng.integers(0, len(specials)))]
+            elif rng.random() < 0.5:
+                del b[at:at + int(rng.integers(1, 40))]
+            else:
+                b = b[:at]
+        txt = bytes(b).split(b"\x00")[0].decode("latin-1")  # the C ABI takes a NUL-terminated string
+        for node in ("render_markovchain", "gbuffer", "accum", "no such node"):
+            _try(mq, lambda: ctx.load_properties_json(txt, node))
+    ctx.close()
