@@ -41,6 +41,8 @@ int mq_launch_volume_sample(const MqSceneDev& sc, const MqParams& P, const MqFra
 int mq_launch_volume_shade(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s);
 int mq_launch_volume_finish(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 // mq_restir.h
+int mq_restir_resident_blocks(int out[4]);
+int mq_launch_restir_wavefront(const MqSceneDev& sc, const MqParams& P, const MqRestirParams& R, const MqRestirFrame& F, const MqFrame& FQ, int which, int round, int grid, hipStream_t s);
 int mq_launch_restir(const MqSceneDev& sc, const MqParams& P, const MqRestirParams& R, const MqRestirFrame& F, int pass, int grid, hipStream_t s);
 
 // mq_post.hip
@@ -90,6 +92,7 @@ struct mq_ctx {
     uint32_t n_local_tiles = 0, tiles_per_rank = 0;
     DevBuf d_out[MQ_OUT_COUNT];
     DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
+    int restir_occ[4] = {0, 0, 0, 0}; // resident blocks per CU of the ReSTIR pass kernels
     bool queues_dirty = true;      // the ray-queue control words have to be zeroed before the next frame uses them
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
     DevBuf d_prev_vdepth, d_dist_mc;
@@ -268,6 +271,7 @@ const PropDesc k_props[] = {
     {"restir: spatital radius", PT_INT, POFF(restir_spatial_radius), false, {}},
     {"restir: spatial bias correction", PT_OPTION, POFF(restir_spatial_bias), false, {"none", "basic", "raytraced"}},
     {"restir: shade visibility", PT_BOOL, POFF(restir_shade_visibility), false, {}},
+    {"inline restir rays", PT_BOOL, POFF(restir_inline_rays), false, {}}, // scheduling of this build: trace the generate / shade rays inside the pass kernels instead of through the queues
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
     {"debug: LC lock statistics", PT_BOOL, POFF(lc_lock_statistics), false, {}},
@@ -1351,7 +1355,14 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
     F.irradiance = (float4*)c->d_out[MQ_OUT_RESTIR_IRRADIANCE].p; F.moments = (float2*)c->d_out[MQ_OUT_RESTIR_MOMENTS].p;
     F.stack_spill = (unsigned long long*)c->d_spill.p;
     uint4* const out = (uint4*)c->d_out[MQ_OUT_RESTIR_RESERVOIRS].p; uint4* const pong = (uint4*)c->d_restir_pong.p;
-    const int grid = std::max(1, c->cu_count) * 2; // 2 blocks per CU at the shading kernels' register budget; the spill area holds grid_blocks >= this
+    if (!c->restir_occ[0]) { // resident blocks per CU of each pass kernel; the spill area holds grid_blocks >= any of these grids
+        int e0 = mq_restir_resident_blocks(c->restir_occ);
+        if (e0) return fail(c, MQ_EHIP, std::string("occupancy query: ") + hipGetErrorString((hipError_t)e0));
+        for (int& o : c->restir_occ) o = std::max(1, o);
+        if (const char* ev = getenv("MQ_DEBUG_RESTIR_BLOCKS_PER_CU")) for (int& o : c->restir_occ) o = std::max(1, atoi(ev)); // tuning experiments only
+    }
+    auto grid_of = [&](int pass) { return std::min(c->grid_blocks, std::max(1, c->cu_count) * c->restir_occ[pass]); };
+    const int grid = grid_of(0);
     const size_t px = (size_t)c->W * c->H;
     int e = 0;
     if (!render) { // renderer_restir.cpp:189-197: the clear pass writes set (1): `reservoirs` = the graph output
@@ -1362,11 +1373,28 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
         // the ping-pong of renderer_restir.cpp:136-146,213-250: the last writer before the shade pass is the graph output
         const bool spatial = q.restir_spatial_iterations > 0;
         F.res_a = spatial ? pong : out; F.res_read = spatial ? out : pong;
-        e = mq_launch_restir(c->scene, c->params, R, F, 0, grid, s);
-        if (!e && q.restir_temporal_reuse && c->restir_iteration > 0) e = mq_launch_restir(c->scene, c->params, R, F, 1, grid, s);
-        if (!e && spatial) { F.res_a = out; F.res_read = pong; e = mq_launch_restir(c->scene, c->params, R, F, 2, grid, s); }
+        // The generate and shade passes trace one closest-hit ray per pixel and sample: as a wavefront through the MCPG
+        // node's queues and traversal kernel ("inline restir rays" = 0, the default), or inline in the pass kernels.
+        const bool wavefront = !q.restir_inline_rays && R.spp + 1 <= MQ_MAX_ROUNDS;
+        MqFrame FQ;
+        if (wavefront) {
+            fill_frame(c, u, FQ);
+            { int r = frame_grids(c, FQ); if (r) return r; }
+            HIPCHK(c, hipMemsetAsync((char*)c->d_ctrl.p + 4 * MQ_CTRL_QUEUE0, 0, ((size_t)MQ_CTRL_WORDS - MQ_CTRL_QUEUE0) * 4, s)); // the rounds' queue tails and fetch heads
+            c->queues_dirty = true; // the MCPG node's next frame starts from zeroed counters
+        }
+        auto traced_pass = [&](int which_a, int round) -> int { // request -> trace -> finish
+            int e2 = mq_launch_restir_wavefront(c->scene, c->params, R, F, FQ, which_a, round, grid_of(which_a == 0 ? 0 : 3), s);
+            if (!e2) e2 = mq_launch_trace_queue(c->scene, FQ, round, false, c->grid_frame[1], s);
+            if (!e2) e2 = mq_launch_restir_wavefront(c->scene, c->params, R, F, FQ, which_a + 1, round, grid_of(which_a == 0 ? 0 : 3), s);
+            return e2;
+        };
+        if (wavefront) { for (int smp = 0; smp < std::max(1, R.spp) && !e; smp++) e = traced_pass(0, smp); }
+        else e = mq_launch_restir(c->scene, c->params, R, F, 0, grid, s);
+        if (!e && q.restir_temporal_reuse && c->restir_iteration > 0) e = mq_launch_restir(c->scene, c->params, R, F, 1, grid_of(1), s);
+        if (!e && spatial) { F.res_a = out; F.res_read = pong; e = mq_launch_restir(c->scene, c->params, R, F, 2, grid_of(2), s); }
         F.res_a = out; F.res_read = pong;
-        if (!e) e = mq_launch_restir(c->scene, c->params, R, F, 3, grid, s);
+        if (!e) e = wavefront ? traced_pass(2, std::max(1, R.spp)) : mq_launch_restir(c->scene, c->params, R, F, 3, grid_of(3), s);
         if (e) return fail(c, MQ_EHIP, std::string("restir launch: ") + hipGetErrorString((hipError_t)e));
     }
     // the graph's delay-1 inputs of the next frame: "reservoirs" and "prev_gbuffer" (renderer_restir.hpp:73-74,86-87)

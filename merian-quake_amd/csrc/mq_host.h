@@ -92,6 +92,7 @@ struct MqProps {
     int restir_temporal_clamp_m = 32 * 20, restir_temporal_bias = 0; float restir_boiling = 0.0f; bool restir_apply_mv = false;
     int restir_spatial_iterations = 0; float restir_spatial_normal_angle = 0.28379410920832787f, restir_spatial_depth = 0.1f;
     int restir_spatial_radius = 30, restir_spatial_bias = 0; bool restir_shade_visibility = false;
+    bool restir_inline_rays = false; // scheduling of this build: generate / shade rays traced inside the pass kernels (the first implementation) instead of as a wavefront through the MCPG node's queues
     // named quirk switches: on = what the reference's shaders compute, off = the evident intent
     bool quirk_lc_max_wo_p = true; // mcpg.comp:170 `max(wo_p, 10)`
     bool quirk_n16_wrap = true;    // mc.glsl:26 `N * N` on a uint16_t (grid.h:19): wraps, 0 at N = 256 / 512 / 768 / 1024

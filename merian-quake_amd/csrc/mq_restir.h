@@ -138,6 +138,149 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_ker
     }
 }
 
+// ---- the same two passes as a wavefront: request the ray -> mq_trace_queue_kernel -> finish ---------------------
+// The generate and shade passes each trace one incoherent closest-hit ray per pixel.  Inline (kernels above / below) the
+// ray is traversed at the register budget of the shading code, one ray per lane to the end of the longest ray of the wave;
+// split, the rays go through the MCPG node's queues (FQ: its ray / hit buffers, slot lists and counters, free between
+// its frames) and its persistent traversal kernel (refill, triangle vote, work sharing).  Pixel slot = tile * 64 + lane,
+// as the MCPG kernels number them.  Arithmetic and the order of the random numbers are those of the inline kernels: the
+// direction is stored and read back as floats, everything else is recomputed from the same inputs.
+// scratch: one u32 per pixel slot (the random-number state between the two halves), in the MCPG node's path records.
+MQ_DEV void restir_emit(const MqFrame& FQ, int round, bool push, uint32_t slot, f3 o, f3 d) {
+    uint32_t q = queue_append(FQ, round, push); // wave-wide: every lane of the wave calls it
+    if (push) {
+        float4* rays = ray_buffer(FQ, round);
+        rays[q] = make_float4(o.x, o.y, o.z, 0.0f);
+        rays[(size_t)FQ.ray_cap + q] = make_float4(d.x, d.y, d.z, 0.0f);
+        FQ.queue_slots[round & 1][q] = slot;
+    }
+}
+// restir_di_generate_samples_bsdf.comp:23-62, sample `smp`: up to the ray
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_a_kernel(MqParams P, MqRestirParams R, MqRestirFrame F, MqFrame FQ, int smp) {
+    const int lane = threadIdx.x & 63;
+    const mq_uniform& U = F.u;
+    uint32_t* scratch = (uint32_t*)FQ.paths;
+    const uint32_t n_waves = gridDim.x * MQ_WAVES;
+    const uint32_t tiles_per_wave = (F.n_tiles + n_waves - 1) / n_waves;
+    for (uint32_t it = 0; it < tiles_per_wave; it++) { // every lane of a wave runs the same trips: the append is wave-wide
+        const uint32_t tile = it * n_waves + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
+        bool push = false; f3 ro = F3(0, 0, 0), wo = F3(0, 0, 1);
+        const uint32_t slot = tile * 64u + (uint32_t)lane;
+        if (tile < F.n_tiles) {
+            const RestirPixel p = restir_pixel(F, tile, lane);
+            if (p.inside) {
+                Hit first; load_chit(F.hits + 10 * p.idx, first);
+                const bool lit = first.albedo.x >= 1e-7f || first.albedo.y >= 1e-7f || first.albedo.z >= 1e-7f;
+                if (lit && smp < R.spp) {
+                    uint32_t rng = smp == 0 ? pcg4d16(p.px, p.py, U.frame * 4u + 0u, R.seed) : scratch[slot];
+                    const float alpha = roughness_to_alpha(first.roughness);
+                    const float x0 = xorshift(rng), x1 = xorshift(rng), x2 = xorshift(rng);
+                    wo = bsdf_sample(first.wi, first.normal, alpha, x0, x1, x2);
+                    const float wodotn = dot(wo, first.normal);
+                    push = !(dot(wo, decode_normal(first.enc_geonormal)) <= 1e-3f || wodotn <= 1e-3f);
+                    ro = first.pos - first.wi * 1e-3f;
+                    scratch[slot] = rng;
+                }
+                if (smp == 0) res_store(F.res_a + 4 * p.idx, res_init()); // the finishing half adds the sample to what is stored
+                if (!push && (smp >= R.spp - 1 || !lit)) { // no sample to wait for: this half finishes the pixel
+                    if (smp == 0 || lit) { Reservoir r = smp == 0 ? res_init() : res_load(F.res_a + 4 * p.idx); res_finalize(r); res_store(F.res_a + 4 * p.idx, r); }
+                }
+            }
+        }
+        restir_emit(FQ, smp, push, slot, ro, wo);
+    }
+}
+// ... from the returned hit on
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_b_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F, MqFrame FQ, int smp) {
+    const mq_uniform& U = F.u;
+    uint32_t* scratch = (uint32_t*)FQ.paths;
+    const QView qv = queue_view(FQ.qctrl + MQ_CTRL_QUEUE0 + smp * MQ_CTRL_GROUP);
+    const uint32_t n = qv.n_eff, stride = gridDim.x * blockDim.x;
+    for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
+        const uint32_t q = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = queue_valid(qv, q < n ? q : 0u);
+        if (!(q < n && valid)) continue;
+        const uint32_t slot = FQ.queue_slots[smp & 1][q];
+        const RestirPixel p = restir_pixel(F, slot >> 6, (int)(slot & 63u));
+        Hit first; load_chit(F.hits + 10 * p.idx, first);
+        const float4 d4 = ray_buffer(FQ, smp)[(size_t)FQ.ray_cap + q];
+        const f3 wo = F3(d4.x, d4.y, d4.z);
+        const uint4 hq = FQ.ray_hits[q];
+        RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
+        const float alpha = roughness_to_alpha(first.roughness);
+        Hit next; next.wi = wo; next.pos = first.pos - first.wi * 1e-3f;
+        next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
+        f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
+        shade_hit(sc, P, U, rhit, throughput, incident, next, F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]));
+        const float dist = length(next.pos - first.pos);
+        const float geo = mmax(dot(next.normal, -wo), 0.0f) / (dist * dist);
+        Reservoir x = res_init();
+        x.pos = next.pos; x.normal = next.normal; x.mv = (next.pos - next.prev_pos) * (1.0f / U.cam_w[3]); x.T = U.cl_time;
+        x.rad[0] = f2h(incident.x); x.rad[1] = f2h(incident.y); x.rad[2] = f2h(incident.z); x.flags = 1u;
+        uint32_t rng = scratch[slot];
+        Reservoir r = res_load(F.res_a + 4 * p.idx);
+        res_add_sample(r, rng, x, geo * bsdf_pdf(first.wi, wo, first.normal, alpha), restir_target_pdf(x, first));
+        scratch[slot] = rng;
+        if (smp >= R.spp - 1) res_finalize(r);
+        res_store(F.res_a + 4 * p.idx, r);
+    }
+}
+// restir_di_shade.comp:21-62 up to the ray
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_a_kernel(MqRestirParams R, MqRestirFrame F, MqFrame FQ, int round) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * MQ_WAVES;
+    const uint32_t tiles_per_wave = (F.n_tiles + n_waves - 1) / n_waves;
+    for (uint32_t it = 0; it < tiles_per_wave; it++) {
+        const uint32_t tile = it * n_waves + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
+        bool push = false; f3 ro = F3(0, 0, 0), wo = F3(0, 0, 1);
+        const uint32_t slot = tile * 64u + (uint32_t)lane;
+        if (tile < F.n_tiles) {
+            const RestirPixel p = restir_pixel(F, tile, lane);
+            if (p.inside) {
+                const Reservoir r = res_load(F.res_a + 4 * p.idx);
+                if (r.flags & 1u) {
+                    Hit first; load_chit(F.hits + 10 * p.idx, first);
+                    wo = normalize(r.pos - first.pos);
+                    ro = first.pos - first.wi * 1e-3f;
+                    push = true;
+                } else { F.irradiance[p.idx] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); F.moments[p.idx] = make_float2(0.0f, 0.0f); }
+            }
+        }
+        restir_emit(FQ, round, push, slot, ro, wo);
+    }
+}
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_b_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F, MqFrame FQ, int round) {
+    const mq_uniform& U = F.u;
+    const QView qv = queue_view(FQ.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const uint32_t n = qv.n_eff, stride = gridDim.x * blockDim.x;
+    for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
+        const uint32_t q = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = queue_valid(qv, q < n ? q : 0u);
+        if (!(q < n && valid)) continue;
+        const uint32_t slot = FQ.queue_slots[round & 1][q];
+        const RestirPixel p = restir_pixel(F, slot >> 6, (int)(slot & 63u));
+        Reservoir r = res_load(F.res_a + 4 * p.idx);
+        Hit first; load_chit(F.hits + 10 * p.idx, first);
+        const f3 dv = r.pos - first.pos;
+        const float4 d4 = ray_buffer(FQ, round)[(size_t)FQ.ray_cap + q];
+        const f3 wo = F3(d4.x, d4.y, d4.z);
+        const uint4 hq = FQ.ray_hits[q];
+        RayHit rhit; rhit.tri = hq.x; rhit.t = __uint_as_float(hq.y); rhit.u = __uint_as_float(hq.z); rhit.v = __uint_as_float(hq.w);
+        Hit next; next.wi = wo; next.pos = first.pos - first.wi * 1e-3f;
+        next.prev_pos = next.pos; next.normal = F3(0, 0, 1); next.enc_geonormal = 0; next.albedo = F3(0, 0, 0); next.roughness = 0.0f;
+        f3 incident = F3(0, 0, 0), throughput = F3(1, 1, 1);
+        shade_hit(sc, P, U, rhit, throughput, incident, next, F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]));
+        f3 irr = F3(0, 0, 0);
+        const float d_sample = length(dv), d_hit = length(first.pos - next.pos);
+        if (R.visibility_shade && fabsf(d_sample - d_hit) / mmax(d_sample, d_hit) > 0.1f) { res_discard(r); res_store(F.res_a + 4 * p.idx, r); } // not visible
+        const float bsdf = bsdf_times_wodotn(first.wi, wo, first.normal, roughness_to_alpha(first.roughness), 0.02f);
+        if (mfinite(r.w)) irr = ((res_radiance(r) * bsdf) * r.w) * (mmax(dot(r.normal, -wo), 0.0f) / (d_sample * d_sample));
+        F.irradiance[p.idx] = make_float4(irr.x, irr.y, irr.z, 1.0f);
+        const float l = luminance(irr);
+        F.moments[p.idx] = make_float2(l, l * l);
+    }
+}
+
 // restir_di_temporal_reuse.comp:71-146 (+ the boiling filter, :37-69, over the 8x8 tile = this wave)
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_temporal_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F) {
     MQ_RESTIR_SETUP
@@ -274,6 +417,25 @@ __global__ void mq_restir_clear_kernel(MqRestirFrame F) {
     }
 }
 
+// resident blocks per CU of the four pass kernels (they are grid-stride loops over tiles: the right grid holds exactly
+// the blocks the chip keeps resident; with 2 per CU instead of 3 / 4 the node took 17 % longer)
+int mq_restir_resident_blocks(int out[4]) {
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[0], mq_restir_generate_kernel, MQ_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[1], mq_restir_temporal_kernel, MQ_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[2], mq_restir_spatial_kernel, MQ_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[3], mq_restir_shade_kernel, MQ_BLOCK, 0);
+    return (int)e;
+}
+// the wavefront halves: which = 0 generate_a, 1 generate_b, 2 shade_a, 3 shade_b; `round` = the queue round they use
+int mq_launch_restir_wavefront(const MqSceneDev& sc, const MqParams& P, const MqRestirParams& R, const MqRestirFrame& F, const MqFrame& FQ, int which, int round, int grid, hipStream_t s) {
+    switch (which) {
+    case 0: mq_restir_generate_a_kernel<<<grid, MQ_BLOCK, 0, s>>>(P, R, F, FQ, round); break;
+    case 1: mq_restir_generate_b_kernel<<<grid, MQ_BLOCK, 0, s>>>(sc, P, R, F, FQ, round); break;
+    case 2: mq_restir_shade_a_kernel<<<grid, MQ_BLOCK, 0, s>>>(R, F, FQ, round); break;
+    default: mq_restir_shade_b_kernel<<<grid, MQ_BLOCK, 0, s>>>(sc, P, R, F, FQ, round); break;
+    }
+    return (int)hipGetLastError();
+}
 int mq_launch_restir(const MqSceneDev& sc, const MqParams& P, const MqRestirParams& R, const MqRestirFrame& F, int pass, int grid, hipStream_t s) {
     switch (pass) {
     case 0: mq_restir_generate_kernel<<<grid, MQ_BLOCK, 0, s>>>(sc, P, R, F); break;

@@ -89,14 +89,16 @@ CASES = [
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("inline_rays", [0, 1], ids=["wavefront", "inline"])
 @pytest.mark.parametrize("name,scene,props", CASES, ids=[c[0] for c in CASES])
-def test_restir_matches_oracle(gpu_ctx, name, scene, props):
+def test_restir_matches_oracle(gpu_ctx, name, scene, props, inline_rays):
     """generate / temporal reuse / spatial reuse / shade over a moving camera: reservoirs (all 64 bytes), irradiance and
-    moments bit-identical to the oracle in every frame; then the clear pass."""
+    moments bit-identical to the oracle in every frame; then the clear pass.  The generate and shade rays either go through
+    the MCPG node's queues and traversal kernel (the default) or are traced inside the pass kernels ("inline restir rays")."""
     import mqhip
     ctx = gpu_ctx
     W, H = 150, 90  # partial tiles on both edges
-    o = setup(ctx, scene, 2 if scene == "synth_sepulcher" else 5, props, W, H)
+    o = setup(ctx, scene, 2 if scene == "synth_sepulcher" else 5, {**props, "inline restir rays": inline_rays}, W, H)
     rp = orc.restir_params_from_ctx(ctx)
     lit = 0.0
     for f in (0, 1, 2, 3, 20):
