@@ -324,8 +324,10 @@ def main():
     c = {key: (v if key == "queue_overflow" else v // n_counted) for key, v in c.items()}
     ctx.enable_counters(False)
     local_pixels = c["pixels"]
+    # the interval after the surface pass: link + apply, and (configs with volume samples) the volume passes
+    upd_name = "mq_apply_kernel" if args.volume_spp <= 0 else "mq_apply_kernel + volume passes"
     kms = {"mq_primary_kernel": det["primary_ms"] / n_detail, "mq_trace_queue_kernel": det["trace_ms"] / n_detail,
-           "mq_bounce_kernel": det["bounce_ms"] / n_detail, "mq_apply_kernel": update_sum / n_timed}
+           "mq_bounce_kernel": det["bounce_ms"] / n_detail, upd_name: update_sum / n_timed}
     rounds = args.spp * 2  # spp * (max path length - 1) launches of trace + bounce per frame
     # algorithmic bytes per kernel class (SURVEY.md 8d prices)
     prim_rays = c["rays"] - c["queue_rays"]
@@ -334,10 +336,10 @@ def main():
         "mq_primary_kernel": local_pixels * 56 + 80 * (c["nodes"] - c["queue_nodes"]) + 48 * (c["tris"] - c["queue_tris"]) + 120 * prim_rays,
         "mq_trace_queue_kernel": 80 * c["queue_nodes"] + 48 * c["queue_tris"] + 48 * c["queue_rays"],   # + 32 B ray in, 16 B hit out
         "mq_bounce_kernel": bounce_rays * (120 + 16 + 4 + 320) + 64 * c["mc_state_reads"] + 24 * c["lc_touches"] + 64 * c["mc_updates_accepted"],
-        "mq_apply_kernel": 128 * c["mc_updates_accepted"],
+        upd_name: 128 * c["mc_updates_accepted"],
     }
     B = algorithmic_bytes(c, local_pixels)
-    launches = {"mq_primary_kernel": 1, "mq_trace_queue_kernel": rounds, "mq_bounce_kernel": rounds, "mq_apply_kernel": 1}
+    launches = {"mq_primary_kernel": 1, "mq_trace_queue_kernel": rounds, "mq_bounce_kernel": rounds, upd_name: 1}
     dom = max(("mq_trace_queue_kernel", "mq_bounce_kernel", "mq_primary_kernel"), key=lambda k: kms[k])  # most device time per frame
     dom_ms_per_launch = kms[dom] / launches[dom]
     dom_bytes_per_launch = kbytes[dom] / launches[dom]
