@@ -91,7 +91,7 @@ struct mq_ctx {
     int rank = 0, world = 1;
     uint32_t n_local_tiles = 0, tiles_per_rank = 0;
     DevBuf d_out[MQ_OUT_COUNT];
-    DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_ctrl, d_counters, d_spill;
+    DevBuf d_mc, d_lc, d_upd_count, d_upd_head, d_queue, d_active, d_active_ctrl, d_ctrl, d_counters, d_spill;
     int restir_occ[4] = {0, 0, 0, 0}; // resident blocks per CU of the ReSTIR pass kernels
     bool queues_dirty = true;      // the ray-queue control words have to be zeroed before the next frame uses them
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
@@ -399,7 +399,7 @@ void props_to_params(mq_ctx* c) {
 
 void free_frame_state(mq_ctx* c) {
     for (auto& b : c->d_out) dev_free(b);
-    dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue);
+    dev_free(c->d_mc); dev_free(c->d_lc); dev_free(c->d_upd_count); dev_free(c->d_upd_head); dev_free(c->d_queue); dev_free(c->d_active); dev_free(c->d_active_ctrl);
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
     dev_free(c->d_restir_pong); dev_free(c->d_restir_prev); dev_free(c->d_restir_prev_gb);
     dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
@@ -881,6 +881,9 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_upd_head, (size_t)c->mc_total * 4))) return r;
     c->queue_cap = (uint32_t)std::min<size_t>(queue_entries_needed(c), 0x7fffffffu);
     if ((r = dev_alloc(c, c->d_queue, (size_t)c->queue_cap * sizeof(MqUpdate)))) return r;
+    if ((r = dev_alloc(c, c->d_active, (size_t)c->queue_cap * 4))) return r;
+    if ((r = dev_alloc(c, c->d_active_ctrl, (size_t)MQ_CTRL_GROUP * 4))) return r;
+    HIPCHK(c, hipMemset(c->d_active_ctrl.p, 0, (size_t)MQ_CTRL_GROUP * 4));
     c->subs = std::min(std::max(1, c->props.pipelines), (int)mq_ctx::MAX_SUBS);
     c->queues_dirty = true;
     if ((r = dev_alloc(c, c->d_ctrl, (size_t)c->subs * MQ_CTRL_WORDS * 4))) return r; // block 0: the rank's (flags, update tails) + sub 0's queues; block k: sub k's queues
@@ -964,7 +967,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     F.gb_albedo = (uint16_t*)c->d_out[MQ_OUT_GB_ALBEDO].p; F.gb_irr = (uint16_t*)c->d_out[MQ_OUT_GB_IRRADIANCE].p;
     F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
     F.mc = (MqMCState*)c->d_mc.p; F.lc = (MqLCCell*)c->d_lc.p; F.upd_count = (uint32_t*)c->d_upd_count.p; F.upd_head = (uint32_t*)c->d_upd_head.p;
-    F.queue = (MqUpdate*)c->d_queue.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.ctrl_words = (uint32_t)(c->d_ctrl.bytes / 4); F.counters = (MqCountersDev*)c->d_counters.p; F.count_stats = c->count_enabled ? 1u : 0u;
+    F.queue = (MqUpdate*)c->d_queue.p; F.active = (uint32_t*)c->d_active.p; F.active_ctrl = (uint32_t*)c->d_active_ctrl.p; F.queue_cap = c->queue_cap; F.ctrl = (uint32_t*)c->d_ctrl.p; F.ctrl_words = (uint32_t)(c->d_ctrl.bytes / 4); F.counters = (MqCountersDev*)c->d_counters.p; F.count_stats = c->count_enabled ? 1u : 0u;
     const size_t k = sub < 0 ? 0 : (size_t)sub, qoff = k * c->sub_ray_cap;
     F.slot_begin = sub < 0 ? 0u : c->sub_slot_begin[sub]; F.slot_end = sub < 0 ? c->n_local_tiles * 64u : c->sub_slot_begin[sub + 1];
     F.qctrl = F.ctrl + k * MQ_CTRL_WORDS;
@@ -1020,8 +1023,10 @@ static int ensure_queue(mq_ctx* c) {
     int r = dev_alloc(c, bigger, (size_t)need * sizeof(MqUpdate));
     if (r) return r;
     HIPCHK(c, hipMemcpy(bigger.p, c->d_queue.p, (size_t)c->queue_cap * sizeof(MqUpdate), hipMemcpyDeviceToDevice));
-    dev_free(c->d_queue);
-    c->d_queue = bigger; c->queue_cap = need;
+    DevBuf list; // (rebuilt by every link pass: nothing to keep)
+    if ((r = dev_alloc(c, list, (size_t)need * 4))) { dev_free(bigger); return r; }
+    dev_free(c->d_queue); dev_free(c->d_active);
+    c->d_queue = bigger; c->d_active = list; c->queue_cap = need;
     return MQ_OK;
 }
 // the learning-write log: room for every write a frame can propose (per segment: one update or invalidation and one
@@ -1471,6 +1476,7 @@ int mq_debug_apply_updates(mq_ctx* c, const void* records, uint32_t n, const mq_
     if (n) HIPCHK(c, hipMemcpy(c->d_queue.p, recs.data(), (size_t)n * sizeof(MqUpdate), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy((uint32_t*)c->d_ctrl.p + MQ_CTRL_UPDATES, ctrl.data(), MQ_CTRL_GROUP * 4, hipMemcpyHostToDevice));
     MqFrame F; fill_frame(c, u, F);
+    HIPCHK(c, hipMemsetAsync(c->d_active_ctrl.p, 0, (size_t)MQ_CTRL_GROUP * 4, nullptr)); // (a frame's first-hit kernel does this)
     int e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, c->props.sequential_update_pass ? c->mc_total : 0u, nullptr);
     if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     HIPCHK(c, hipMemsetAsync((uint32_t*)c->d_ctrl.p + MQ_CTRL_UPDATES, 0, MQ_CTRL_GROUP * 4, nullptr));

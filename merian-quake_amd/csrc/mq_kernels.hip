@@ -1217,6 +1217,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
     const float Wf = (float)F.W, Hf = (float)F.H;
     const f3 gb_sun = P.gbuffer_hide_sun ? F3(0.0f, 0.0f, 0.0f) : F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
+    if (blockIdx.x == 0 && threadIdx.x < MQ_SHARDS && F.slot_begin == 0u) F.active_ctrl[threadIdx.x * MQ_SHARD_STRIDE] = 0u; // the link pass of this frame lists from 0 (the last frame's apply pass is done)
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (total - F.slot_begin + stride - 1) / stride;
     PSTART(ctr);
@@ -1977,17 +1978,23 @@ MQ_DEV void mc_update(MCS& s, f3 pos, float w, f3 target, const uint16_t* mv) { 
 // pass A: chain the queue entries of each slot (newest first) through `next`
 __global__ __launch_bounds__(256) void mq_link_kernel(MqFrame F) {
     const QView qv = queue_view(F.ctrl + MQ_CTRL_UPDATES);
-    if (blockIdx.x == 0 && threadIdx.x < MQ_SHARDS) F.ctrl[MQ_CTRL_SNAP + threadIdx.x] = F.ctrl[MQ_CTRL_UPDATES + threadIdx.x * MQ_SHARD_STRIDE];
     const uint32_t n = qv.n_eff < F.queue_cap ? qv.n_eff : F.queue_cap;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
         const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
         const bool valid = queue_valid(qv, i < n ? i : 0u);
-        if (!(i < n && valid)) continue;
-        uint32_t* e3 = (uint32_t*)(F.queue + i) + 12;
-        if (e3[2] == MQ_NIL) continue; // an update dropped by the per-slot cap
-        uint32_t prev = atomicExch(&F.upd_head[e3[2]], i + 1u);
-        e3[3] = prev;
+        bool first = false; uint32_t slot = MQ_NIL;
+        if (i < n && valid) {
+            uint32_t* e3 = (uint32_t*)(F.queue + i) + 12;
+            slot = e3[2];
+            if (slot != MQ_NIL) { // (MQ_NIL: an update dropped by the per-slot cap)
+                const uint32_t prev = atomicExch(&F.upd_head[slot], i + 1u);
+                e3[3] = prev;
+                first = prev == 0u; // the slot's first linked entry lists the slot for the apply pass
+            }
+        }
+        const uint32_t at = shard_append(F.active_ctrl, first); // wave-wide; 16 tails: one counter would serialise ~40 k appends per frame
+        if (first) { if (at < F.queue_cap) F.active[at] = slot; else atomicOr(&F.ctrl[0], 2u); } // cannot happen (the list is sized like the queue, whose entries it indexes); flagged, never silent
     }
 }
 
@@ -2045,9 +2052,9 @@ MQ_DEV uint32_t apply_slot(const MqParams& P, const MqFrame& F, uint32_t slot, u
     return n_applied;
 }
 
-// The apply pass reads the update-queue tails from the snapshot the link pass left (MQ_CTRL_SNAP), so its first block
-// can zero the live control words of every queue of the frame right away -- the ray queues were consumed by the bounce
-// kernels before it, the update queue is being consumed by this pass -- and the next frame needs no fill launch.  (A
+// The apply pass works from the list of slots the link pass left (F.active) and reads no queue tail, so
+// its first block can zero the live control words of every queue of the frame right away -- the ray queues were consumed
+// by the bounce kernels before it, the update queue by the link pass -- and the next frame needs no fill launch.  (A
 // "last block done" counter would do too, but 2048 blocks bumping one address cost +70 us on this eight-die part.)
 MQ_DEV void reset_queue_control(const MqFrame& F) {
     if (blockIdx.x == 0) for (uint32_t w = MQ_CTRL_UPDATES + threadIdx.x; w < F.ctrl_words; w += blockDim.x) F.ctrl[w] = 0u;
@@ -2056,18 +2063,19 @@ MQ_DEV void reset_queue_control(const MqFrame& F) {
 // pass B: the newest entry of a slot leads and replays compute_updates.comp:56-124 for the slot's
 // first MQ_MAX_UPDATES arrivals (the reference drops later arrivals at enqueue time, mc.glsl:169-184)
 __global__ __launch_bounds__(256) void mq_apply_kernel(MqParams P, MqFrame F) {
-    const QView qv = queue_view(F.ctrl + MQ_CTRL_SNAP, 1u);
-    const uint32_t n = qv.n_eff < F.queue_cap ? qv.n_eff : F.queue_cap;
+    // one thread per slot the link pass listed (every thread has work: a frame with volume samples queues millions of
+    // entries for a third as many slots, and walking the entries to find each slot's newest one took 3x the rounds)
+    const QView av = queue_view(F.active_ctrl);
+    const uint32_t n_active = av.n_eff < F.queue_cap ? av.n_eff : F.queue_cap;
     uint32_t accepted = 0;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
-        const uint32_t i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool valid = queue_valid(qv, i < n ? i : 0u);
-        if (!(i < n && valid)) continue;
-        const uint32_t slot = ((const uint4*)(F.queue + i))[3].z;
-        if (slot == MQ_NIL) continue; // dropped by the cap at enqueue (counted there)
-        if (*(volatile uint32_t*)&F.upd_head[slot] != i + 1u) continue;
-        accepted += apply_slot(P, F, slot, i);
+    for (uint32_t it = 0; it < (n_active + stride - 1) / stride; it++) {
+        const uint32_t j = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = queue_valid(av, j < n_active ? j : 0u); // (wave-wide)
+        if (!(j < n_active && valid)) continue;
+        const uint32_t slot = F.active[j];
+        const uint32_t head = F.upd_head[slot];
+        if (head != 0u) accepted += apply_slot(P, F, slot, head - 1u);
     }
     // statistics: updates applied this frame (those dropped by the cap are counted where they are dropped, at enqueue)
     for (int off = 32; off > 0; off >>= 1) accepted += __shfl_down(accepted, off, 64);

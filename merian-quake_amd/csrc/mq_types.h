@@ -31,7 +31,6 @@
 #define MQ_SHARD_STRIDE 32                                  // words between the counters of two shards (128 B)
 #define MQ_MAX_ROUNDS 30
 #define MQ_CTRL_GROUP (MQ_SHARDS * MQ_SHARD_STRIDE)         // words of one sharded counter
-#define MQ_CTRL_SNAP 32                                     // the update-queue tails as the link pass saw them (16 words, one per shard): what the apply pass reads
 #define MQ_CTRL_UPDATES MQ_CTRL_GROUP                       // update-queue tails (group 1; group 0 holds the overflow flag)
 #define MQ_CTRL_QUEUE0 (2 * MQ_CTRL_GROUP)                  // ray-queue tails, one group per round
 #define MQ_CTRL_HEAD0 (MQ_CTRL_QUEUE0 + (MQ_MAX_ROUNDS + 1) * MQ_CTRL_GROUP) // traversal fetch heads (64-entry blocks), one group per round
@@ -218,6 +217,8 @@ struct MqFrame {
     uint32_t* upd_count;   // per mc slot: entries queued this frame (soft cap at enqueue, exact cap in the update pass)
     uint32_t* upd_head;    // per mc slot, index+1 of the newest queue entry
     MqUpdate* queue;
+    uint32_t* active;      // slots with queued updates, listed by the link pass for the apply pass (queue_cap entries, sharded like the queues)
+    uint32_t* active_ctrl; // its 16 sharded tails (one MQ_CTRL_GROUP of words), zeroed by the frame's first-hit kernel
     uint32_t queue_cap;
     // control words: see MQ_CTRL_* (sharded tails of the update queue and of every round's ray queue, fetch heads).
     // ctrl: the rank's block (overflow flags, update-queue tails); qctrl: the block of this launch's sub-pipeline (its
