@@ -31,7 +31,7 @@ int mq_launch_apply(const MqParams& P, const MqFrame& F, int grid, uint32_t sequ
 int mq_launch_debug_view(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
 int mq_stack_lds_entries();
 int mq_launch_stream_read(const void* src, size_t bytes, uint32_t* sink, int grid, hipStream_t s);
-int mq_resident_blocks(bool guided, bool merged_trace, size_t shade_lds_bytes, int shade_block, int out[4]);
+int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int shade_block, int out[4]);
 int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
 int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s);
@@ -995,10 +995,10 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
 // grid is exactly the number of blocks the chip holds at once (CUs x resident blocks per CU at the
 // kernel's register and LDS footprint): a larger grid runs as a ragged last wave of blocks.
 static int frame_grids(mq_ctx* c, const MqFrame& F) {
-    const int key = (int)F.lds_rows2 * 4 + (c->params.reference_mode ? 1 : 0) + (c->world > 1 ? 2 : 0);
+    const int key = (int)F.lds_rows2 * 2 + (c->params.reference_mode ? 1 : 0);
     if (c->grid_key == key) return MQ_OK;
     int occ[4] = {0, 0, 0, 0};
-    int e = mq_resident_blocks(!c->params.reference_mode, c->world > 1, (size_t)F.lds_rows2 * 64 * 8 * (F.shade_block / 64), (int)F.shade_block, occ);
+    int e = mq_resident_blocks(!c->params.reference_mode, (size_t)F.lds_rows2 * 64 * 8 * (F.shade_block / 64), (int)F.shade_block, occ);
     if (e) return fail(c, MQ_EHIP, std::string("occupancy query: ") + hipGetErrorString((hipError_t)e));
     for (int i = 0; i < 4; i++) {
 #if MQ_GRID_MODE == 0

@@ -1316,15 +1316,11 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 #ifndef MQ_SHARE
 #define MQ_SHARE 1 // idle lanes adopt subtrees of busy lanes once the queue is exhausted (see the kernel)
 #endif
-// MERGED: the step of the loop visits a node and tests a triangle side by side (one memory latency per step, 106 registers);
-// otherwise the two phases follow each other (two latencies, 80 registers).  A full frame keeps the chip's gather path and
-// its vector ALUs busy whichever way -- the phased loop is 3 % faster there --, a rank of a partitioned frame has few
-// rays per wave and runs at the latency of its longest ray: the merged step is 15 % faster there.  The host picks.
 #ifndef MQ_OCC_TRACEQ
 #define MQ_OCC_TRACEQ MQ_OCC_TRACE
 #endif
-template <bool MERGED, bool COUNT>
-__global__ __launch_bounds__(MQ_BLOCK, MERGED ? 4 : MQ_OCC_TRACEQ) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
+template <bool COUNT>
+__global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACEQ) void mq_trace_queue_kernel(MqSceneDev sc, MqFrame F, int round) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
     const int lane = threadIdx.x & 63;
 #ifdef MQ_PROF
@@ -1467,63 +1463,6 @@ __global__ __launch_bounds__(MQ_BLOCK, MERGED ? 4 : MQ_OCC_TRACEQ) void mq_trace
         }
         PLAP(ctr, 26);
         if (__ballot(busy) == 0ull) { if (exhausted) break; else continue; }
-        if (MERGED) {
-        // One step: the triangle test of the leaf found LAST step and the next node visit run side by side -- their
-        // records are requested together (one memory latency per step instead of two) and a lane with a single pending
-        // triangle does both.  The triangle phase is still taken by wave vote (only when enough lanes have triangles
-        // pending, or no lane could do anything else), so the expensive test executes at useful occupancy; the
-        // triangle test comes before the box test, which therefore culls with the closest hit so far.
-        const bool has_tri = busy && t.tmask != 0;
-        const uint32_t ntri = (uint32_t)__popcll(__ballot(has_tri));
-        const uint32_t nwork = (uint32_t)__popcll(__ballot(busy && !fin));
-        const bool do_tri = has_tri && (ntri >= MQ_TRI_VOTE || ntri == nwork);
-        const bool do_node = busy && !fin && t.G.y > 0x00ffffffu && (t.tmask == 0 || (do_tri && (t.tmask & (t.tmask - 1u)) == 0u));
-#ifdef MQ_PROF
-        { const uint32_t nn = (uint32_t)__popcll(__ballot(do_node)), nb = (uint32_t)__popcll(__ballot(busy)), nt = (uint32_t)__popcll(__ballot(do_tri));
-          if (nn) { ctr.prof[12]++; ctr.prof[13] += nn; } if (nt) { ctr.prof[14]++; ctr.prof[15] += nt; } ctr.prof[11]++; ctr.prof[30] += nb;
-          if (exhausted && pool_i == pool_len) { ctr.prof[22]++; ctr.prof[23] += nb; } }
-#endif
-        // Both records are requested by EVERY lane, in straight-line code (a lane without a triangle / node to visit asks
-        // for record 0: one shared line, nearly free): the number of loads in flight is then the same on every path, so
-        // the triangle test waits for the triangle only and runs under the latency of the node record.  (Requests
-        // inside the divergent branches make the compiler wait for everything at the join.)
-        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-        uint32_t tri_id = 0;
-        if (do_tri) {
-            const uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
-            t.tmask &= t.tmask - 1u;
-            tri_id = t.tbase + k;
-            if (COUNT) ctr.tris++;
-        }
-        const uint4* np = (const uint4*)sc.nodes;
-        if (do_node) {
-            np = trav_node_pop(sc, t, stk, spill);
-            if (COUNT) ctr.nodes++;
-        }
-        const u4v* tp = (const u4v*)(sc.tris + tri_id);
-        u4v ta = tp[0], tb = tp[1], tc = tp[2];
-        __builtin_amdgcn_sched_barrier(0); // the triangle first: loads return in order
-        uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        PLAP(ctr, 27);
-        if (do_tri) {
-            float tt = 0.0f, u = 0.0f, v = 0.0f;
-            bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(ta.x), __uint_as_float(ta.y), __uint_as_float(ta.z)),
-                                    F3(__uint_as_float(ta.w), __uint_as_float(tb.x), __uint_as_float(tb.y)),
-                                    F3(__uint_as_float(tb.z), __uint_as_float(tb.w), __uint_as_float(tc.x)), tt, u, v);
-            accept = accept && (tt < MQ_T_MAX) && (tt < t.hit.t || (tt == t.hit.t && tc.y < t.best_key));
-            if (accept && (tc.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, tri_id, u, v);
-            if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = tri_id; t.best_key = tc.y; t.tlim = trav_limit(tt); }
-        }
-        if (do_node) {
-            trav_node_test(t, n0, n1, n2, n3, n4);
-            (void)trav_next(t, stk, spill); // group exhausted: the next one comes off the stack now
-        }
-        PLAP(ctr, 28);
-#ifdef MQ_PROF
-        if (busy) ray_iters++;
-#endif
-        if (busy && !fin) fin = !(t.G.y > 0x00ffffffu) && t.tmask == 0;
-        } else {
         // node phase: lanes without pending triangles visit one node
         const bool want_node = busy && !fin && t.tmask == 0;
 #ifdef MQ_PROF
@@ -1549,7 +1488,6 @@ __global__ __launch_bounds__(MQ_BLOCK, MERGED ? 4 : MQ_OCC_TRACEQ) void mq_trace
         if (busy) ray_iters++;
 #endif
         if (busy && !fin && t.tmask == 0) fin = trav_next(t, stk, spill);
-        }
         if (SHARE) { // finished helpers hand their closest hit to the owner lane, one at a time (wave-uniform loop)
             unsigned long long hm = __ballot(busy && fin && owner >= 0);
             while (hm) {
@@ -2252,10 +2190,7 @@ int mq_launch_primary_trace(const MqSceneDev& sc, const MqParams& P, const MqFra
 }
 int mq_packet_stack_entries() { return MQ_PKT_STACK; }
 int mq_launch_trace_queue(const MqSceneDev& sc, const MqFrame& F, int round, bool count, int grid, hipStream_t s) {
-    const bool merged = F.world > 1u; // a rank of a partitioned frame: see the kernel
-    if (count) mq_trace_queue_kernel<false, true><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
-    else if (merged) mq_trace_queue_kernel<true, false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
-    else mq_trace_queue_kernel<false, false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
+    if (count) mq_trace_queue_kernel<true><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round); else mq_trace_queue_kernel<false><<<grid, MQ_BLOCK, 0, s>>>(sc, F, round);
     return (int)hipGetLastError();
 }
 int mq_launch_bounce(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int round, bool guided, bool count, int grid, hipStream_t s) {
@@ -2331,14 +2266,13 @@ int mq_render_block_size() { return MQ_BLOCK; }
 int mq_spill_entries() { return MQ_SPILL_ENTRIES; }
 int mq_stack_lds_entries() { return MQ_STACK_LDS; }
 // resident blocks per CU of the three frame kernels at the given dynamic LDS size: {primary, trace, bounce}
-int mq_resident_blocks(bool guided, bool merged_trace, size_t shade_lds_bytes, int shade_block, int out[4]) {
+int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int shade_block, int out[4]) {
     int a = 0, b = 0, c = 0, d = 0;
     hipError_t e;
     if (guided) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<true, false>, shade_block, shade_lds_bytes);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, mq_primary_kernel<false, false>, shade_block, shade_lds_bytes);
     if (e != hipSuccess) return (int)e;
-    if (merged_trace) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<true, false>, MQ_BLOCK, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false, false>, MQ_BLOCK, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, mq_trace_queue_kernel<false>, MQ_BLOCK, 0);
     if (e != hipSuccess) return (int)e;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, mq_primary_trace_lanes_kernel, MQ_BLOCK, 0);
     if (e != hipSuccess) return (int)e;
