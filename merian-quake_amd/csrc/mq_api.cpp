@@ -143,6 +143,7 @@ struct mq_ctx {
     hipStream_t pt_stream = nullptr;
     DevBuf d_prim_hits[2];
     hipEvent_t ev_pt_done[2] = {}, ev_shaded[2] = {};
+    hipEvent_t ev_bounced = nullptr; bool bounced_valid = false; // the last bounce kernel of the previous frame has been issued ("update pass" overlap: the camera rays start behind it)
     bool shaded_valid[2] = {false, false};
     uint32_t frame_parity = 0;
     hipEvent_t ev_pt_t[EV_RING][2] = {}; // start / end of the camera-ray launch on pt_stream (frames with per-launch events)
@@ -278,7 +279,7 @@ const PropDesc k_props[] = {
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
-    {"overlap camera rays", PT_OPTION, POFF(overlap_camera_rays), false, {"off", "partitioned frames", "always"}},
+    {"overlap camera rays", PT_OPTION, POFF(overlap_camera_rays), false, {"off", "auto", "always", "update pass"}},
     {"camera rays: frustum packets", PT_BOOL, POFF(packet_camera_rays), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
@@ -404,7 +405,7 @@ void free_frame_state(mq_ctx* c) {
     dev_free(c->d_restir_pong); dev_free(c->d_restir_prev); dev_free(c->d_restir_prev_gb);
     dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
     dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0; dev_free(c->d_lc_stats); dev_free(c->d_last_upd);
-    dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); c->shaded_valid[0] = c->shaded_valid[1] = false;
+    dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); c->shaded_valid[0] = c->shaded_valid[1] = false; c->bounced_valid = false;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
@@ -481,6 +482,7 @@ int mq_create(mq_ctx** out, int device) {
             }
         }
         for (int k = 0; ok && k < 2; k++) ok = hipEventCreateWithFlags(&c->ev_pt_done[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_shaded[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_bounced, hipEventDisableTiming) == hipSuccess;
         for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) ok = ok && hipEventCreate(&e4) == hipSuccess;
         if (!ok) { delete c; return MQ_EHIP; }
     }
@@ -498,6 +500,7 @@ void mq_destroy(mq_ctx* c) {
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
         if (c->pt_stream) (void)hipStreamDestroy(c->pt_stream);
         for (int k = 0; k < 2; k++) { if (c->ev_pt_done[k]) (void)hipEventDestroy(c->ev_pt_done[k]); if (c->ev_shaded[k]) (void)hipEventDestroy(c->ev_shaded[k]); }
+        if (c->ev_bounced) (void)hipEventDestroy(c->ev_bounced);
         for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) if (e4) (void)hipEventDestroy(e4);
         for (int k = 0; k < mq_ctx::MAX_SUBS - 1; k++) { if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); if (c->side[k]) (void)hipStreamDestroy(c->side[k]); }
     }
@@ -1109,11 +1112,16 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     // The camera rays of this frame do not wait for the previous frame: the host runs ahead of the device, so this
     // launch executes beside the previous frame's kernels and fills the tails of their launches.  It waits only for
     // the first-hit kernel that last read the hit buffer of this parity (two frames ago).
-    const bool overlap_pt = (c->props.overlap_camera_rays == 2 || (c->props.overlap_camera_rays == 1 && c->world > 1)) && !c->count_enabled;
+    const int ov = c->props.overlap_camera_rays; // off / auto / always / update pass
+    const bool overlap_pt = ov != 0 && !c->count_enabled;
+    // "update pass" (auto on a full frame): the camera rays start behind the previous frame's last bounce kernel, i.e. beside
+    // its update pass only -- latency bound, with little vector-ALU work, where the rest of a full frame is issue bound
+    const bool behind_bounces = ov == 3 || (ov == 1 && c->world == 1);
     const uint32_t parity = c->frame_parity & 1u;
     c->ev_pt_timed[slot] = overlap_pt && detail;
     if (overlap_pt) {
         if (c->shaded_valid[parity]) HIPCHK(c, hipStreamWaitEvent(c->pt_stream, c->ev_shaded[parity], 0));
+        if (behind_bounces && c->bounced_valid) HIPCHK(c, hipStreamWaitEvent(c->pt_stream, c->ev_bounced, 0));
         if (detail) HIPCHK(c, hipEventRecord(c->ev_pt_t[slot][0], c->pt_stream));
     }
     auto join = [&]() -> int {
@@ -1152,6 +1160,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
             if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
         }
         if (r == rounds - 1) { int rr = join(); if (rr) return rr; } // every chain is done before the render interval ends
+        if (r == rounds - 1 && overlap_pt) { HIPCHK(c, hipEventRecord(c->ev_bounced, s)); c->bounced_valid = true; }
         if (r < timed && (detail || r == timed - 1)) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s)); // the last one ends the render interval
     }
     if (c->params.debug_output_connected) { // mcpg.comp:212-277: part of the surface pass, i.e. before the update pass

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SMALL = {"adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16}
-SETTINGS = [(1, "off"), (2, "off"), (4, "off"), (1, "always"), (3, "always")]
+SETTINGS = [(1, "off"), (2, "off"), (4, "off"), (1, "always"), (3, "always"), (1, "update pass"), (2, "auto")]
 
 
 def _outputs(ctx):
@@ -57,10 +57,10 @@ def test_reference_mode_outputs_do_not_depend_on_scheduling(mqlib, sync_every_fr
 
 
 def test_partitioned_rank_outputs_do_not_depend_on_camera_ray_overlap(mqlib):
-    """"partitioned frames" (the default) switches the overlap on for a rank of a tile partition."""
+    """"auto" (the default) overlaps from the start of the previous frame for a rank of a tile partition."""
     props = {"reference mode": 1, "spp": 1, "max path length": 3}
     a = _render(mqlib, props, 1, "off", 6, False, partition=(1, 3))
-    b = _render(mqlib, props, 1, "partitioned frames", 6, False, partition=(1, 3))
+    b = _render(mqlib, props, 1, "auto", 6, False, partition=(1, 3))
     _same(a, b, "rank 1 of 3")
 
 
