@@ -1114,9 +1114,16 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     // the first-hit kernel that last read the hit buffer of this parity (two frames ago).
     const int ov = c->props.overlap_camera_rays; // off / auto / always / update pass
     const bool overlap_pt = ov != 0 && !c->count_enabled;
-    // "update pass" (auto on a full frame): the camera rays start behind the previous frame's last bounce kernel, i.e. beside
-    // its update pass only -- latency bound, with little vector-ALU work, where the rest of a full frame is issue bound
-    const bool behind_bounces = ov == 3 || (ov == 1 && c->world == 1);
+    // Where the camera rays of the NEXT frame may start among this frame's launches T0 B0 T1 B1 ... link apply (they run on a
+    // low-priority stream and fill what those leave idle): "always" = with the frame; "update pass" = behind the last bounce
+    // kernel, i.e. beside link / apply only; "auto" = behind the second-to-last bounce kernel, i.e. beside the last round and
+    // the update pass -- the drain of the last trace launch, the terminal bounce kernel (bound by gathers) and the update
+    // pass (latency bound) leave the vector ALUs the camera rays need; the first round is issue bound itself.
+    // Measured per frame at 1 / 2 / 4 / 8 ranks: off 2.03 / - / - / 0.61, always 2.04 / 1.17 / 0.70 / 0.46, update pass 2.00 / - / - / -,
+    // auto 1.93 / 1.10 / 0.66 / 0.46 ms.
+    const bool behind_bounces = ov == 1 || ov == 3;
+    static const int pt_behind_env = getenv("MQ_DEBUG_PT_BEHIND") ? atoi(getenv("MQ_DEBUG_PT_BEHIND")) : -1; // tuning experiments only
+    const int pt_behind = std::min(std::max(pt_behind_env >= 0 ? pt_behind_env : (ov == 3 ? 0 : 2), 0), std::max(0, 2 * rounds - 1));
     const uint32_t parity = c->frame_parity & 1u;
     c->ev_pt_timed[slot] = overlap_pt && detail;
     if (overlap_pt) {
@@ -1155,12 +1162,14 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
             if (e) return fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e));
         }
         if (r < timed && detail) HIPCHK(c, hipEventRecord(ev[3 + 2 * r], s));
+        // launches of this frame in order: T0 B0 T1 B1 ...; `behind` counts back from the last one (0 = the last bounce kernel)
+        if (overlap_pt && 2 * r == 2 * rounds - 1 - pt_behind) { HIPCHK(c, hipEventRecord(c->ev_bounced, s)); c->bounced_valid = true; }
         for (int k = 0; k < S; k++) {
             e = mq_launch_bounce(c->scene, c->params, FS[k], r, guided, c->count_enabled, sub_grid(2), st(k));
             if (e) return fail(c, MQ_EHIP, std::string("bounce launch: ") + hipGetErrorString((hipError_t)e));
         }
         if (r == rounds - 1) { int rr = join(); if (rr) return rr; } // every chain is done before the render interval ends
-        if (r == rounds - 1 && overlap_pt) { HIPCHK(c, hipEventRecord(c->ev_bounced, s)); c->bounced_valid = true; }
+        if (overlap_pt && 2 * r + 1 == 2 * rounds - 1 - pt_behind) { HIPCHK(c, hipEventRecord(c->ev_bounced, s)); c->bounced_valid = true; }
         if (r < timed && (detail || r == timed - 1)) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s)); // the last one ends the render interval
     }
     if (c->params.debug_output_connected) { // mcpg.comp:212-277: part of the surface pass, i.e. before the update pass
