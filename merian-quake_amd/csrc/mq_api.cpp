@@ -279,7 +279,7 @@ const PropDesc k_props[] = {
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
-    {"overlap camera rays", PT_OPTION, POFF(overlap_camera_rays), false, {"off", "auto", "always", "update pass"}},
+    {"overlap camera rays", PT_OPTION, POFF(overlap_camera_rays), false, {"off", "auto", "always", "update pass", "last round"}},
     {"camera rays: frustum packets", PT_BOOL, POFF(packet_camera_rays), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
@@ -1112,18 +1112,21 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     // The camera rays of this frame do not wait for the previous frame: the host runs ahead of the device, so this
     // launch executes beside the previous frame's kernels and fills the tails of their launches.  It waits only for
     // the first-hit kernel that last read the hit buffer of this parity (two frames ago).
-    const int ov = c->props.overlap_camera_rays; // off / auto / always / update pass
+    const int ov = c->props.overlap_camera_rays; // off / auto / always / update pass / last round
     const bool overlap_pt = ov != 0 && !c->count_enabled;
     // Where the camera rays of the NEXT frame may start among this frame's launches T0 B0 T1 B1 ... link apply (they run on a
     // low-priority stream and fill what those leave idle): "always" = with the frame; "update pass" = behind the last bounce
-    // kernel, i.e. beside link / apply only; "auto" = behind the second-to-last bounce kernel, i.e. beside the last round and
-    // the update pass -- the drain of the last trace launch, the terminal bounce kernel (bound by gathers) and the update
-    // pass (latency bound) leave the vector ALUs the camera rays need; the first round is issue bound itself.
+    // kernel, i.e. beside link / apply only; "last round" = behind the second-to-last bounce kernel, i.e. beside the last
+    // round and the update pass -- the drain of the last trace launch, the terminal bounce kernel (bound by gathers) and the
+    // update pass (latency bound) leave the vector ALUs the camera rays need; the first round is issue bound itself.
     // Measured per frame at 1 / 2 / 4 / 8 ranks: off 2.03 / - / - / 0.61, always 2.04 / 1.17 / 0.70 / 0.46, update pass 2.00 / - / - / -,
-    // auto 1.93 / 1.10 / 0.66 / 0.46 ms.
-    const bool behind_bounces = ov == 1 || ov == 3;
+    // last round 1.93 / 1.10 / 0.66 / 0.46 ms.  "auto": last round for a rank of a partitioned frame; update pass for a full
+    // frame, where it keeps every kernel of the surface pass alone on the chip (their times stay those of the kernels) for
+    // 3 % of the frame time.
+    const int mode = ov == 1 ? (c->world > 1 ? 4 : 3) : ov;
+    const bool behind_bounces = mode == 3 || mode == 4;
     static const int pt_behind_env = getenv("MQ_DEBUG_PT_BEHIND") ? atoi(getenv("MQ_DEBUG_PT_BEHIND")) : -1; // tuning experiments only
-    const int pt_behind = std::min(std::max(pt_behind_env >= 0 ? pt_behind_env : (ov == 3 ? 0 : 2), 0), std::max(0, 2 * rounds - 1));
+    const int pt_behind = std::min(std::max(pt_behind_env >= 0 ? pt_behind_env : (mode == 3 ? 0 : 2), 0), std::max(0, 2 * rounds - 1));
     const uint32_t parity = c->frame_parity & 1u;
     c->ev_pt_timed[slot] = overlap_pt && detail;
     if (overlap_pt) {

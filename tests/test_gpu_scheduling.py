@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SMALL = {"adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16}
-SETTINGS = [(1, "off"), (2, "off"), (4, "off"), (1, "always"), (3, "always"), (1, "update pass"), (2, "auto")]
+SETTINGS = [(1, "off"), (2, "off"), (4, "off"), (1, "always"), (3, "always"), (1, "update pass"), (2, "auto"), (1, "last round")]
 
 
 def _outputs(ctx):
