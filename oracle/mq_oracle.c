@@ -752,8 +752,8 @@ static void decompress_hit(const chit_t* c, hit_t* h) { /* hit.glsl.h:45-53 */
     h->roughness = orc_h2f(c->roughness);
 }
 
-/* gbuffer.comp:75-131 (mip-mapped first-hit texturing is not restated: LOD 0 is used, i.e.
- * "enable albedo mipmap"/"enable emission mipmap" = false) */
+/* gbuffer.comp:75-131, with the mip-mapped first-hit texturing of raytrace.glsl:232-245,299-303: r_x / r_y are the
+ * directions of the camera rays one pixel to the right / below ("enable albedo mipmap" / "enable emission mipmap") */
 static void gbuffer_pixel(tls_t* tl, uint32_t px, uint32_t py) {
     orc_ctx* c = (orc_ctx*)tl->c;
     const orc_uniform_t* u = &c->u;
