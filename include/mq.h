@@ -336,6 +336,26 @@ int mq_bsp_model_count(const mq_ctx* ctx); /* brush models of the BSP loaded by 
 int mq_load_mdl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* alias_model, uint32_t* next_texnum);
 int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* sprite_model, uint32_t* next_texnum);
 
+/* ---- per-frame uniform and constants producer: QuakeNode::process, src/game/quake_node.cpp:742-824 ----------------
+ * What the Quake node reads from quakespasm each frame, as a plain struct; mq_uniform_update turns the PREVIOUS frame's
+ * uniform in *u into this frame's (previous camera = last camera, time difference, fog coefficients, sky texture numbers,
+ * player flags), mq_constants_fov the two field-of-view constants.  Pure host arithmetic, no context. */
+typedef struct mq_frame_state {
+    float vieworg[3], viewangles[3]; /* r_refdef.vieworg / viewangles (pitch, yaw, roll in degrees) */
+    double cl_time;                  /* cl.time */
+    uint32_t frame;                  /* frames since the last worldspawn */
+    int32_t render;                  /* render_info.render: a map is loaded and drawn */
+    int32_t has_player, weapon, waterlevel; /* sv_player != nullptr, sv_player->v.weapon / waterlevel (demos have no player) */
+    int32_t sky_mode;                /* 0: no sky textures, 1: skybox (sky[0..5] = rt bk lf ft up dn), 2: classic (sky[0] solid, sky[1] alpha layer) */
+    uint16_t sky[6], notexture;      /* texture numbers; notexture->texnum fills what a mode leaves open */
+    int32_t mu_overwrite;            /* the node's "overwrite mu_t / mu_s" switch with its values, else Quake's fog */
+    float mu_t, mu_s_div_mu_t[3];
+    float fog_density, fog_color[3]; /* Fog_GetDensity(), Fog_GetColor() */
+} mq_frame_state;
+enum { MQ_PLAYER_FLAGS_TORCH = 1, MQ_PLAYER_FLAGS_UNDERWATER = 2 }; /* res/shader/config.h:39-40 */
+int mq_uniform_update(mq_uniform* u, const mq_frame_state* in); /* quake_node.cpp:768-824 */
+int mq_constants_fov(mq_constants* k, float fov_x_degrees);     /* quake_node.cpp:762-765 */
+
 #ifdef __cplusplus
 }
 #endif

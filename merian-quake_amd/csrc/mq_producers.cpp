@@ -395,3 +395,40 @@ int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_
 }
 
 } // extern "C"
+
+// ---- per-frame uniform: QuakeNode::process, quake_node.cpp:768-824 ---------------------------------------------------
+extern "C" int mq_uniform_update(mq_uniform* u, const mq_frame_state* in) {
+    if (!u || !in) return MQ_EINVAL;
+    uint32_t flags = 0; // :770-779 (one flags byte, three padding bytes)
+    if (in->render && in->has_player) flags = (in->weapon == 1 ? (uint32_t)MQ_PLAYER_FLAGS_TORCH : 0u) | (in->waterlevel >= 3 ? (uint32_t)MQ_PLAYER_FLAGS_UNDERWATER : 0u);
+    u->player = flags;
+    u->frame = in->frame;
+    memcpy(u->prev_cam_x, u->cam_x, 16); memcpy(u->prev_cam_w, u->cam_w, 16); memcpy(u->prev_cam_u, u->cam_u, 16); // :781-783
+    V3 f, r, up; angle_vectors(in->viewangles, f, r, up);                                                      // :784-786
+    u->cam_w[0] = f.x; u->cam_w[1] = f.y; u->cam_w[2] = f.z;
+    u->cam_u[0] = up.x; u->cam_u[1] = up.y; u->cam_u[2] = up.z;
+    u->cam_x[0] = in->vieworg[0]; u->cam_x[1] = in->vieworg[1]; u->cam_x[2] = in->vieworg[2]; u->cam_x[3] = 1.0f; // :787
+    uint16_t sky[6]; for (uint16_t& t : sky) t = in->notexture;                                                 // :788-799
+    if (in->render && in->sky_mode == 1) for (int i = 0; i < 6; i++) sky[i] = in->sky[i];
+    else if (in->render && in->sky_mode == 2) { sky[0] = in->sky[0]; sky[1] = in->sky[1]; sky[2] = 0xffffu; }
+    u->sky_rt_bk = (uint32_t)sky[0] | ((uint32_t)sky[1] << 16); u->sky_lf_ft = (uint32_t)sky[2] | ((uint32_t)sky[3] << 16); u->sky_up_dn = (uint32_t)sky[4] | ((uint32_t)sky[5] << 16);
+    if (in->mu_overwrite) {                                                                                    // :801-805
+        u->cam_x[3] = in->mu_t;
+        u->prev_cam_x[3] = in->mu_s_div_mu_t[0] * in->mu_t; u->prev_cam_w[3] = in->mu_s_div_mu_t[1] * in->mu_t; u->prev_cam_u[3] = in->mu_s_div_mu_t[2] * in->mu_t;
+    } else {                                                                                                   // :806-816
+        u->cam_x[3] = std::pow(in->fog_density, 2.f) * 0.1f;
+        u->prev_cam_x[3] = std::pow(in->fog_color[0], 1.f / 1.2f) * u->cam_x[3];
+        u->prev_cam_w[3] = std::pow(in->fog_color[1], 1.f / 1.2f) * u->cam_x[3];
+        u->prev_cam_u[3] = std::pow(in->fog_color[2], 1.f / 1.2f) * u->cam_x[3];
+    }
+    const float time_diff = (float)(in->cl_time - (double)u->cl_time);                                         // :817-823 (cl.time is a double, the uniform a float)
+    u->cam_w[3] = time_diff > 0 ? time_diff : 1.0f;
+    u->cl_time = (float)in->cl_time;
+    return MQ_OK;
+}
+extern "C" int mq_constants_fov(mq_constants* k, float fov_x_degrees) { // :762-765
+    if (!k) return MQ_EINVAL;
+    k->fov = fov_x_degrees;
+    k->fov_tan_alpha_half = std::tan(fov_x_degrees * (3.14159265358979323846f / 180.0f) / 2);
+    return MQ_OK;
+}

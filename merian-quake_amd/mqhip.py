@@ -77,6 +77,12 @@ class SpriteInstance(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("prev_origin", C.c_float * 3), ("angles", C.c_float * 3), ("scale", C.c_float), ("frame", C.c_int32)]
 
 
+class FrameState(C.Structure):
+    _fields_ = [("vieworg", C.c_float * 3), ("viewangles", C.c_float * 3), ("cl_time", C.c_double), ("frame", C.c_uint32), ("render", C.c_int32),
+                ("has_player", C.c_int32), ("weapon", C.c_int32), ("waterlevel", C.c_int32), ("sky_mode", C.c_int32), ("sky", C.c_uint16 * 6), ("notexture", C.c_uint16),
+                ("mu_overwrite", C.c_int32), ("mu_t", C.c_float), ("mu_s_div_mu_t", C.c_float * 3), ("fog_density", C.c_float), ("fog_color", C.c_float * 3)]
+
+
 class MqError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("mq error %d: %s" % (code, msg))
@@ -152,6 +158,8 @@ def load_library(path=None):
         "mq_bsp_model_count": (i32, [P]),
         "mq_load_mdl": (i32, [P, C.c_char_p, C.c_char_p, u32, C.POINTER(i32), u32p]),
         "mq_load_spr": (i32, [P, C.c_char_p, C.c_char_p, u32, C.POINTER(i32), u32p]),
+        "mq_uniform_update": (i32, [C.POINTER(Uniform), C.POINTER(FrameState)]),
+        "mq_constants_fov": (i32, [C.POINTER(Constants), C.c_float]),
         "mq_post_process": (i32, [P, vp]),
         "mq_restir_process": (i32, [P, C.POINTER(Uniform), i32, vp]),
         "mq_post_clear": (i32, [P]),
@@ -506,3 +514,11 @@ class Context:
         out = np.empty((n, n_out), np.float32)
         self._chk(self.lib.mq_math_eval(self.h, op, _ptr(inp), _ptr(out), n))
         return out
+
+
+def uniform_update(lib, uniform, state):
+    """QuakeNode::process's per-frame uniform (quake_node.cpp:768-824): `uniform` holds the previous frame's on entry"""
+    r = lib.mq_uniform_update(C.byref(uniform), C.byref(state))
+    if r < 0:
+        raise MqError(r, "mq_uniform_update")
+    return uniform

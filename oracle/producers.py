@@ -239,3 +239,37 @@ def add_brush_model(g, model_geo, origin, angles, prev_origin, prev_angles):
     pw = (vtx[:, :1] * PR[:, 0] + vtx[:, 1:2] * PR[:, 1]) + vtx[:, 2:3] * PR[:, 2] + PT
     g.vtx += list(w.astype(np.float32).reshape(-1)); g.prev += list(pw.astype(np.float32).reshape(-1))
     g.idx += list(base + idx.reshape(-1)); g.ext.append(ext)
+
+
+def uniform_update(prev, st):
+    """QuakeNode::process, quake_node.cpp:768-824: this frame's UniformData from the previous frame's (`prev`: dict with
+    cam_x[4], cam_w[4], cam_u[4], cl_time) and the frame state `st` (dict, the fields of mq_frame_state).  float32 like the C++."""
+    u = {}
+    flags = 0
+    if st["render"] and st["has_player"]:
+        flags = (1 if st["weapon"] == 1 else 0) | (2 if st["waterlevel"] >= 3 else 0)
+    u["player"] = flags
+    u["frame"] = st["frame"]
+    u["prev_cam_x"] = np.array(prev["cam_x"], np.float32); u["prev_cam_w"] = np.array(prev["cam_w"], np.float32); u["prev_cam_u"] = np.array(prev["cam_u"], np.float32)
+    f, _, up = angle_vectors(st["viewangles"])
+    u["cam_w"] = np.array([f[0], f[1], f[2], 0], np.float32); u["cam_u"] = np.array([up[0], up[1], up[2], prev["cam_u"][3]], np.float32)
+    u["cam_x"] = np.array([st["vieworg"][0], st["vieworg"][1], st["vieworg"][2], 1], np.float32)
+    sky = [st["notexture"]] * 6
+    if st["render"] and st["sky_mode"] == 1:
+        sky = list(st["sky"])
+    elif st["render"] and st["sky_mode"] == 2:
+        sky[0], sky[1], sky[2] = st["sky"][0], st["sky"][1], 0xffff
+    u["sky"] = sky
+    if st["mu_overwrite"]:
+        mu_t = F(st["mu_t"])
+        u["cam_x"][3] = mu_t
+        ms = [F(F(st["mu_s_div_mu_t"][k]) * mu_t) for k in range(3)]
+    else:
+        mu_t = F(F(np.power(F(st["fog_density"]), F(2))) * F(0.1))
+        u["cam_x"][3] = mu_t
+        ms = [F(F(np.power(F(st["fog_color"][k]), F(1) / F(1.2))) * mu_t) for k in range(3)]
+    u["prev_cam_x"][3], u["prev_cam_w"][3], u["prev_cam_u"][3] = ms
+    dt = F(np.float64(st["cl_time"]) - np.float64(F(prev["cl_time"])))
+    u["cam_w"][3] = dt if dt > 0 else F(1)
+    u["cl_time"] = F(st["cl_time"])
+    return u

@@ -224,3 +224,43 @@ def test_bsp_scene_with_per_frame_entities_renders_like_the_oracle(mqlib, tmp_pa
         moved = moved or bool(f and (ctx.read_output(mqhip.OUT_GB_MV) != 0).any())
     assert lit > 0 and moved
     ctx.close()
+
+
+def test_per_frame_uniform_matches_oracle(mq, mqlib):
+    """mq_uniform_update (QuakeNode::process, quake_node.cpp:768-824) over a sequence of frames: camera and previous
+    camera, time difference (1 when the clock stands), fog coefficients from Quake's fog or from the override, sky texture
+    numbers by sky mode, player flags; mq_constants_fov."""
+    rng = np.random.default_rng(9)
+    lib = mqlib if hasattr(mqlib, "mq_uniform_update") else mq.load_library()
+    u = mq.Uniform()
+    prev = dict(cam_x=[0, 0, 0, 0], cam_w=[0, 0, 0, 0], cam_u=[0, 0, 0, 0], cl_time=0.0)
+    t = 0.0
+    for frame in range(12):
+        st = dict(vieworg=[float(x) for x in rng.uniform(-500, 500, 3)], viewangles=[float(x) for x in rng.uniform(-180, 180, 3)],
+                  cl_time=t, frame=frame, render=int(frame != 3), has_player=int(frame % 4 != 1), weapon=int(rng.integers(1, 3)), waterlevel=int(rng.integers(0, 4)),
+                  sky_mode=frame % 3, sky=[int(x) for x in rng.integers(1, 4000, 6)], notexture=7, mu_overwrite=int(frame % 5 == 4), mu_t=0.003,
+                  mu_s_div_mu_t=[0.9, 0.8, 0.7], fog_density=float(rng.uniform(0, 0.3)), fog_color=[float(x) for x in rng.uniform(0, 1, 3)])
+        s = mq.FrameState()
+        for k, v in st.items():
+            if isinstance(v, list):
+                for i, x in enumerate(v):
+                    getattr(s, k)[i] = x
+            else:
+                setattr(s, k, v)
+        mq.uniform_update(lib, u, s)
+        ref = P.uniform_update(prev, st)
+        for name in ("cam_x", "cam_w", "cam_u", "prev_cam_x", "prev_cam_w", "prev_cam_u"):
+            got = np.array(list(getattr(u, name)), np.float32)
+            want = ref[name] if name != "cam_u" else np.array(list(ref[name][:3]) + [got[3]], np.float32)  # cam_u.w is not written (stays whatever it was)
+            assert np.allclose(got, want, rtol=2e-6, atol=1e-7), (frame, name, got, want)
+        assert abs(u.cl_time - ref["cl_time"]) <= 1e-6 * max(1.0, abs(ref["cl_time"]))
+        assert u.frame == ref["frame"] and u.player == ref["player"]
+        sky = [u.sky_rt_bk & 0xffff, u.sky_rt_bk >> 16, u.sky_lf_ft & 0xffff, u.sky_lf_ft >> 16, u.sky_up_dn & 0xffff, u.sky_up_dn >> 16]
+        assert sky == ref["sky"], (frame, sky, ref["sky"])
+        if frame > 0:
+            assert u.cam_w[3] > 0
+        prev = dict(cam_x=list(u.cam_x), cam_w=list(u.cam_w), cam_u=list(u.cam_u), cl_time=u.cl_time)
+        t += 0.0 if frame == 5 else float(rng.uniform(0.005, 0.05))  # one frame with a standing clock: time difference 1
+    k = mq.Constants()
+    assert lib.mq_constants_fov(__import__("ctypes").byref(k), 90.0) == 0
+    assert abs(k.fov_tan_alpha_half - 1.0) < 1e-6 and k.fov == 90.0
