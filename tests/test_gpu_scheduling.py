@@ -138,3 +138,49 @@ def test_restir_node_between_frames_does_not_disturb_the_mcpg_node(mqlib):
     b = _frames_with_restir(mqlib, vol, 1, scene="synth_start_fog")
     assert a[2] == 0 and b[2] == 0 and a[1][..., :3].sum() > 0
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def test_reset_reconnect_and_repartition_with_frames_in_flight(mqlib):
+    """State changes between frames while the host runs ahead of the device (camera rays of the next frame in flight on the
+    side stream): mq_reset_state, a reconnect at another size, a new partition -- the frames after each change equal those
+    of a fresh context that starts there (reference mode)."""
+    import mqhip
+    props = {"randomize seed": 0, "seed": 0x5EED, **SMALL, "reference mode": 1, "spp": 1, "max path length": 3}
+
+    def fresh(W, H, partition, frames):
+        c = mqhip.Context(0)
+        c.header_defaults(); c.synth_scene("synth_start", 4)
+        for k, v in props.items():
+            c.set_property(k, v)
+        c.commit()
+        if partition:
+            c.set_partition(*partition)
+        c.connect(W, H)
+        for f in frames:
+            c.process(c.synth_camera(f))
+        out = (c.irradiance().copy(), c.read_output(mqhip.OUT_TILES).copy())
+        c.close()
+        return out
+
+    c = mqhip.Context(0)
+    c.header_defaults(); c.synth_scene("synth_start", 4)
+    for k, v in props.items():
+        c.set_property(k, v)
+    c.commit(); c.connect(328, 200)
+    for f in range(5):
+        c.process(c.synth_camera(f))
+    c.reset_state()
+    for f in (7, 8):
+        c.process(c.synth_camera(f))
+    a = c.irradiance().copy()
+    assert np.array_equal(a.view(np.uint32), fresh(328, 200, None, (7, 8))[0].view(np.uint32))
+    c.connect(200, 136)
+    for f in (9, 10, 11):
+        c.process(c.synth_camera(f))
+    assert np.array_equal(c.irradiance().view(np.uint32), fresh(200, 136, None, (9, 10, 11))[0].view(np.uint32))
+    c.set_partition(1, 3); c.connect(200, 136)
+    for f in (12, 13):
+        c.process(c.synth_camera(f))
+    assert np.array_equal(c.read_output(mqhip.OUT_TILES), fresh(200, 136, (1, 3), (12, 13))[1])
+    assert c.counters()["queue_overflow"] == 0
+    c.close()
