@@ -980,6 +980,10 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     F.prim_hits = (uint4*)c->d_prim_hits[c->frame_parity & 1].p;
     F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p + qoff; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p + qoff;
     F.ray_cap = sub < 0 ? c->ray_cap : c->sub_ray_cap;
+    { // test hook: tell the kernels of a smaller queue than the one allocated, so that the overflow path (rays dropped, frame flagged) runs
+        static const int div = getenv("MQ_DEBUG_RAY_CAP_DIV") ? std::max(1, atoi(getenv("MQ_DEBUG_RAY_CAP_DIV"))) : 1;
+        if (div > 1) F.ray_cap = std::max(1024u, F.ray_cap / (uint32_t)div);
+    }
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
     F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
     F.lc_stats = (uint2*)c->d_lc_stats.p; F.last_upd_count = (uint32_t*)c->d_last_upd.p;

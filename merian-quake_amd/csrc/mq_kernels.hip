@@ -1412,7 +1412,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACEQ) void mq_trace_queue_kernel
             PLAP(ctr, 25);
             const uint32_t avail = pool_len - pool_i;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!busy && rank < avail) {
+            // (a position past the buffer was never written -- queue_append drops such a ray and raises the overflow flag --: skipped)
+            if (!busy && rank < avail && shard_pos(pool_s, (pool_j << 6) + pool_i + rank) < F.ray_cap) {
                 const uint32_t i = pool_i + rank;
                 q = shard_pos(pool_s, (pool_j << 6) + i); // the lane is busy from here on
                 const float4* rays = ray_buffer(F, round);
@@ -1538,7 +1539,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
     float* lobes = GUIDED ? (float*)(s_dyn + (size_t)(threadIdx.x >> 6) * F.lds_rows2 * 64) + (threadIdx.x & 63) : nullptr;
     const mq_uniform& U = F.u;
     const QView qv = queue_view(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
-    const uint32_t n = qv.n_eff;
+    const uint32_t n = qv.n_eff < F.ray_cap ? qv.n_eff : F.ray_cap; // (positions past the buffer were never written, see queue_append)
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -1827,7 +1828,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
     const QView qv = queue_view(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
-    const uint32_t n = qv.n_eff;
+    const uint32_t n = qv.n_eff < F.ray_cap ? qv.n_eff : F.ray_cap; // (positions past the buffer were never written, see queue_append)
     const uint32_t grid_max_x = F.W / (uint32_t)P.distance_mc_grid_width + 1u;
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     const f3 mu_s = F3(U.prev_cam_x[3], U.prev_cam_w[3], U.prev_cam_u[3]);

@@ -1,8 +1,12 @@
 """Scheduling options of this build (no reference counterpart: "pipelines", "overlap camera rays", the rank partition)
 decide WHEN launches run, never what they compute: the node outputs are bit-identical for every setting, in reference
 mode and for guided frames rendered from a given (frozen) learning state."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -184,3 +188,31 @@ def test_reset_reconnect_and_repartition_with_frames_in_flight(mqlib):
     assert np.array_equal(c.read_output(mqhip.OUT_TILES), fresh(200, 136, (1, 3), (12, 13))[1])
     assert c.counters()["queue_overflow"] == 0
     c.close()
+
+
+def test_ray_queue_overflow_is_flagged_not_fatal(mqlib):
+    """A ray queue that is too small (cannot happen with the 2x + 1024 sizing; forced here by MQ_DEBUG_RAY_CAP_DIV, which tells the
+    kernels of a quarter of the positions that are allocated) drops rays and raises overflow bit 1: no access past the
+    queue, finite output, and the frame is recognisable as invalid.  Runs in a child process (the variable is read once)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import mqhip
+c = mqhip.Context(0)
+c.header_defaults(); c.synth_scene("synth_start", 4)
+for k, v in {"randomize seed": 0, "seed": 0x5EED, "adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16,
+             "reference mode": 0, "spp": 2, "max path length": 4, "volume spp": 1, "particle size": 7.0}.items():
+    c.set_property(k, v)
+c.commit(); c.connect(640, 360)
+for f in range(4):
+    c.process(c.synth_camera(f))
+img = c.irradiance()
+print("RESULT", int(c.counters()["queue_overflow"]), bool(np.isfinite(img).all()), float(img[..., :3].sum()) > 0)
+c.close()
+""" % os.path.join(ROOT, "merian-quake_amd")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MQ_DEBUG_RAY_CAP_DIV="4"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert int(line[1]) & 1 and line[2] == "True" and line[3] == "True", line
