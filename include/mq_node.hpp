@@ -120,6 +120,9 @@ class RendererMarkovChainHIP {
         check(mq_dyn_add_brush_model(ctx_, model, origin, angles, prev_origin, prev_angles));
     }
     void dyn_end(int slot) { check(mq_dyn_end(ctx_, slot)); scene_dirty_ = true; }
+    // the Quake node's per-frame uniform (QuakeNode::process, quake_node.cpp:768-824): `info.uniform` holds the previous frame's
+    // on entry and this frame's on return; `info.render` follows the frame state
+    void update_uniform(RenderInfo& info, const mq_frame_state& frame) { check(mq_uniform_update(&info.uniform, &frame)); info.render = frame.render != 0; }
 
     // shared by the adapters of the other nodes that live on this context
     NodeStatusFlags visit_properties(Properties& config, const std::string& prefix) {

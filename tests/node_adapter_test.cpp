@@ -52,6 +52,18 @@ int main() {
     mq::RenderInfo info;
     try { node.process(info, nullptr); } catch (const mq::Error& e) { threw = e.code == MQ_ENODEVICE; }
     REQUIRE(threw);
+    { // the per-frame uniform producer through the adapter
+        mq::RenderInfo ri; memset(&ri.uniform, 0, sizeof ri.uniform);
+        mq_frame_state fs; memset(&fs, 0, sizeof fs);
+        fs.vieworg[0] = 10; fs.viewangles[1] = 90; fs.cl_time = 2.5; fs.frame = 7; fs.render = 1; fs.has_player = 1; fs.weapon = 1; fs.waterlevel = 3;
+        fs.sky_mode = 2; fs.sky[0] = 11; fs.sky[1] = 12; fs.notexture = 5; fs.mu_overwrite = 1; fs.mu_t = 0.01f; fs.mu_s_div_mu_t[0] = 0.5f;
+        node.update_uniform(ri, fs);
+        REQUIRE(ri.render && ri.uniform.frame == 7 && ri.uniform.player == 3u && ri.uniform.cam_x[0] == 10.0f && ri.uniform.cam_x[3] == 0.01f);
+        REQUIRE(ri.uniform.sky_rt_bk == (11u | (12u << 16)) && ri.uniform.sky_lf_ft == (0xffffu | (5u << 16)) && ri.uniform.cam_w[3] == 2.5f);
+        REQUIRE(ri.uniform.cam_w[1] > 0.999f && ri.uniform.prev_cam_x[3] == 0.005f);
+        fs.cl_time = 2.5; node.update_uniform(ri, fs); // the clock stands: time difference 1, previous camera = last camera
+        REQUIRE(ri.uniform.cam_w[3] == 1.0f && ri.uniform.prev_cam_x[0] == 10.0f);
+    }
     // the ReSTIR node and the post chain on the same context: the reference's own key strings, prefix stripped
     mq::RendererRESTIRHIP restir(node);
     REQUIRE(restir.describe_inputs().size() == 13);
