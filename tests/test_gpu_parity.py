@@ -584,7 +584,7 @@ def test_debug_views_match_oracle(gpu_ctx):
         ctx.set_property("debug output connected", 0)
 
 
-@pytest.mark.parametrize("mc_samples", [None, 12, 30])
+@pytest.mark.parametrize("mc_samples", [None, 0, 12, 30])
 def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx, mc_samples):
     """The WHOLE guided estimator (K Markov-chain lookups with validation and motion extrapolation, lobe selection,
     vMF / BSDF sampling, the MIS pdf mixture, light-cache reads, the learning computations and their RNG draws) is
@@ -601,7 +601,8 @@ def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx, mc_samples):
         o.process(ctx.synth_camera(f), threads=1)
     ctx.process(ctx.synth_camera(0))  # the first device frame zeroes the tables; state can be written after it
     omc, olc = o.state(0), o.state(1)
-    assert (omc["sum_w"] > 0).sum() > 1000 and (olc["N"] > 0).sum() > 1000  # something was learned
+    assert (olc["N"] > 0).sum() > 1000  # something was learned
+    assert (omc["sum_w"] > 0).sum() > (1000 if mc_samples != 0 else -1)  # (no Markov-chain samples: no update passes the acceptance test x * score_sum < f * 0, mcpg.comp:172; the light cache still learns)
     gmc = np.zeros(len(omc), mqhip.Context.MC_DTYPE)
     gmc["w_tgt"] = omc["w_tgt"]; gmc["sum_w"] = omc["sum_w"]; gmc["w_cos"] = omc["w_cos"]; gmc["T"] = omc["T"]; gmc["id"] = omc["id"]
     gmc["n_hash"] = omc["N"].astype(np.uint32) | (omc["hash"].astype(np.uint32) << 16); gmc["mv"] = omc["mv"]
