@@ -515,8 +515,18 @@ def _copy_learned_state(ctx, o, with_distance=False):
     return gmc, glc
 
 
+VOLUME_VARIANTS = [{"volume: use LC": 0}, {"Phase Prob": 0.9}, {"dist guide p": 0.1}, {"volume spp": 4, "particle size": 3.0}, {"dist mc grid width": 10, "dist mc states per vertex": 4}]
+
+
+@pytest.mark.parametrize("variant", VOLUME_VARIANTS, ids=[",".join("%s=%s" % kv for kv in v.items()) for v in VOLUME_VARIANTS])
+def test_guided_volume_frame_from_given_state_parameter_variants(gpu_ctx, variant):
+    """The volume estimator's parameters away from their defaults (no light cache at the scatter point, mostly phase-function
+    sampling, mostly transmittance sampling, more samples of another particle size, another distance grid)."""
+    test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx, None, variant)
+
+
 @pytest.mark.parametrize("samples", [None, (30, 30), (7, 30)])
-def test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx, samples):
+def test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx, samples, variant=None):
     """The same for a config-4 style frame: surface guiding + single-scatter volume estimator with its distance and
     direction Markov chains (volume.comp:34-238), from the oracle's learned state, stores switched off.  `samples`:
     ("mc samples", "dist mc samples") up to the top of the reference's range (render_mcpg.cpp:460,494: 0..30), where the
@@ -525,6 +535,7 @@ def test_guided_volume_frame_from_given_state_is_bit_exact(gpu_ctx, samples):
     ctx = gpu_ctx
     W, H = 112, 72
     more = {} if samples is None else {"mc samples": samples[0], "dist mc samples": samples[1]}
+    more.update(variant or {})
     o = make_pair(ctx, "synth_start_fog", 7, {"reference mode": 0, "spp": 1, "max path length": 3, **VOL, "volume forward project": 0, **more}, W, H)  # forward projection would feed the previous frame's learned depth in
     for f in range(5):
         o.process(ctx.synth_camera(f), threads=1)
@@ -584,8 +595,21 @@ def test_debug_views_match_oracle(gpu_ctx):
         ctx.set_property("debug output connected", 0)
 
 
+GUIDED_VARIANTS = [
+    {"max path length": 2}, {"max path length": 5, "spp": 1}, {"surf: use LC": 0}, {"adaptive grid type": "quadratic", "LC grid type": "quadratic"},
+    {"mc fast recovery": 0}, {"adaptive grid prob": 0.0}, {"adaptive grid prob": 1.0}, {"BSDF Prob": 0.9}, {"ML Prior": 3.0, "quirk: LC max(wo_p,10)": 0},
+]
+
+
+@pytest.mark.parametrize("variant", GUIDED_VARIANTS, ids=[",".join("%s=%s" % kv for kv in v.items()) for v in GUIDED_VARIANTS])
+def test_guided_frame_from_given_state_parameter_variants(gpu_ctx, variant):
+    """The same for the estimator's parameters away from their defaults: path lengths 2 and 5, no light-cache tail, the
+    quadratic grids, no fast recovery, one grid only, mostly BSDF sampling, another prior / the light-cache quirk off."""
+    test_guided_frame_from_given_state_is_bit_exact(gpu_ctx, None, variant)
+
+
 @pytest.mark.parametrize("mc_samples", [None, 0, 12, 30])
-def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx, mc_samples):
+def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx, mc_samples, variant=None):
     """The WHOLE guided estimator (K Markov-chain lookups with validation and motion extrapolation, lobe selection,
     vMF / BSDF sampling, the MIS pdf mixture, light-cache reads, the learning computations and their RNG draws) is
     deterministic once the learning state is given and its stores are switched off: the oracle learns for a few
@@ -596,6 +620,8 @@ def test_guided_frame_from_given_state_is_bit_exact(gpu_ctx, mc_samples):
     props = {"reference mode": 0, "spp": 2, "max path length": 3, **SMALL}
     if mc_samples is not None:  # the reference's range is 0..30 (render_mcpg.cpp:460)
         props["mc samples"] = mc_samples
+    if variant:
+        props.update(variant)
     o = make_pair(ctx, "synth_start", 11, props, W, H)
     for f in range(5):  # the oracle learns (sequential frame: deterministic)
         o.process(ctx.synth_camera(f), threads=1)
