@@ -124,6 +124,36 @@ def test_surface_learning_writes_match_oracle(gpu_ctx, quirk_n16):
         ctx.set_property("quirk: 16-bit N*N", 1)
 
 
+LEARN_VARIANTS = [{"mc fast recovery": 0}, {"surf: use LC": 0}, {"adaptive grid type": "quadratic", "LC grid type": "quadratic"},
+                  {"quirk: LC max(wo_p,10)": 0}, {"max path length": 5, "spp": 1}, {"adaptive grid prob": 0.0}, {"mc samples": 12}]
+
+
+@pytest.mark.parametrize("variant", LEARN_VARIANTS, ids=[",".join("%s=%s" % kv for kv in v.items()) for v in LEARN_VARIANTS])
+def test_surface_learning_writes_parameter_variants(gpu_ctx, variant):
+    """The same multiset comparison of the proposed learning writes with the estimator's parameters away from their defaults."""
+    ctx = gpu_ctx
+    W, H = 128, 80
+    props = {"reference mode": 0, "spp": 2, "max path length": 3, **SMALL, **variant}
+    o = learned_pair(ctx, "synth_start", 11, props, W, H, 5)
+    _copy_learned_state(ctx, o)
+    ctx.set_property("debug: freeze learning", 1); ctx.set_property("debug: log learning writes", 1)
+    try:
+        o.set_params(orc.params_from_ctx(ctx, ctx.get_constants()))
+        u = ctx.synth_camera(5)
+        o.learn_log_reset(W * H * 32)
+        ctx.process(u); o.process(u, threads=8)
+        assert np.array_equal(ctx.irradiance().view(np.uint32), o.irradiance().view(np.uint32))
+        glog, olog = by_kind(ctx.learn_log()), by_kind(o.learn_log())
+        for kind, name in ((KIND_UPDATE, "update records"), (KIND_LC, "light-cache stores"), (KIND_RECOVER, "fast-recovery invalidations")):
+            assert_logs_equal(glog[kind], olog[kind], name)
+        assert len(olog[KIND_UPDATE]) > 100 and len(olog[KIND_LC]) > 1000
+        if variant.get("mc fast recovery", 1) == 0:
+            assert len(olog[KIND_RECOVER]) == 0
+    finally:
+        ctx.set_property("debug: freeze learning", 0); ctx.set_property("debug: log learning writes", 0)
+        ctx.header_defaults()
+
+
 def test_volume_learning_writes_match_oracle(gpu_ctx):
     """The same for a frame with the single-scatter volume estimator: its Markov-chain updates (jittered pseudo-normal,
     volume.comp:218-224), invalidations (:226-229) and distance-chain stores (:201-215) join the surface pass's."""
