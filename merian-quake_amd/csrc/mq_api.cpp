@@ -1113,9 +1113,9 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         HIPCHK(c, hipEventRecord(c->ev_fork, s));
         for (int k = 1; k < S; k++) HIPCHK(c, hipStreamWaitEvent(st(k), c->ev_fork, 0));
     }
-    // The camera rays of this frame do not wait for the previous frame: the host runs ahead of the device, so this
-    // launch executes beside the previous frame's kernels and fills the tails of their launches.  It waits only for
-    // the first-hit kernel that last read the hit buffer of this parity (two frames ago).
+    // The camera rays of this frame need not wait for the previous frame: the host runs ahead of the device, so this
+    // launch can execute beside the previous frame's kernels.  For correctness it waits only for the first-hit kernel that
+    // last read the hit buffer of this parity (two frames ago); WHERE in the previous frame it starts is a matter of speed:
     const int ov = c->props.overlap_camera_rays; // off / auto / always / update pass / last round
     const bool overlap_pt = ov != 0 && !c->count_enabled;
     // Where the camera rays of the NEXT frame may start among this frame's launches T0 B0 T1 B1 ... link apply (they run on a
