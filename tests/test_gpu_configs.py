@@ -102,3 +102,19 @@ def test_config4_tears_4spp_volume_tiled(gpu_ctx, config4_oracle, world, rank):
     finally:
         ctx.set_property("debug: freeze learning", 0)
         ctx.set_partition(0, 1)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (8, 8), (9, 17), (3, 64)])
+def test_tiny_images_match_oracle(gpu_ctx, W, H):
+    """Images smaller than a wave's tile, of one tile, and with partial tiles on both edges: unguided frames and the first
+    guided frame (zeroed chains: deterministic) bit-identical to the oracle, no queue overflow."""
+    ctx = gpu_ctx
+    for ref in (1, 0):
+        o = make_pair(ctx, "synth_tiny", 2, {"reference mode": ref, "spp": 2, "max path length": 3}, W, H)
+        for f in range(3):
+            u = ctx.synth_camera(f)
+            ctx.process(u); o.process(u, threads=1)
+            if ref or f == 0:
+                assert np.array_equal(ctx.irradiance().view(np.uint32), o.irradiance().view(np.uint32)), (W, H, ref, f)
+        assert ctx.counters()["queue_overflow"] == 0
+        o.close()
