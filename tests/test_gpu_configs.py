@@ -118,3 +118,36 @@ def test_tiny_images_match_oracle(gpu_ctx, W, H):
                 assert np.array_equal(ctx.irradiance().view(np.uint32), o.irradiance().view(np.uint32)), (W, H, ref, f)
         assert ctx.counters()["queue_overflow"] == 0
         o.close()
+
+
+@pytest.mark.parametrize("what", ["no geometry", "per-frame geometry only"])
+def test_degenerate_scenes_match_oracle(gpu_ctx, what):
+    """A scene without any triangle (every ray sees the sky), and one whose only triangles are in a per-frame slot (no static
+    tree: every ray starts in the per-frame tree): unguided frames, the first guided frame and all g-buffer outputs
+    bit-identical to the oracle."""
+    import mqhip
+    ctx = gpu_ctx
+    for ref in (1, 0):
+        ctx.header_defaults()
+        ctx.synth_scene("synth_tiny", 2)
+        geo = [ctx.get_geometry(s) for s in range(16)]
+        for s in range(16):
+            ctx.set_geometry(s, np.zeros((0, 3), np.float32), None, np.zeros((0, 3), np.uint32), np.zeros(0, mqhip.EXT_DTYPE), 0)
+        if what == "per-frame geometry only":
+            g = next(g for g in geo if g is not None)
+            ctx.set_geometry(2, g["vtx"], g["prev_vtx"], g["idx"], g["ext"], 0)  # flags 0: not static, alpha tests apply
+        for k, v in {"randomize seed": 0, "seed": 0x5EED, **SMALL, "reference mode": ref, "spp": 1, "max path length": 3}.items():
+            ctx.set_property(k, v)
+        ctx.commit(); ctx.connect(96, 56)
+        o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))
+        orc.mirror_scene(ctx, o); o.commit(1); o.connect(96, 56)
+        for f in range(2):
+            u = ctx.synth_camera(f)
+            ctx.process(u); o.process(u, threads=1)
+            if ref or f == 0:
+                assert np.array_equal(ctx.irradiance().view(np.uint32), o.irradiance().view(np.uint32)), (what, ref, f)
+                for wg, wo, name in ((mqhip.OUT_GB_ALBEDO, orc.OUT_GB_ALBEDO, "albedo"), (mqhip.OUT_GB_IRRADIANCE, orc.OUT_GB_IRRADIANCE, "gb irradiance"), (mqhip.OUT_GB_MV, orc.OUT_GB_MV, "mv"),
+                                     (mqhip.OUT_GBUFFER, orc.OUT_GBUFFER, "gbuffer"), (mqhip.OUT_HITS, orc.OUT_HITS, "hits")):
+                    assert np.array_equal(ctx.read_output(wg), o.output(wo)), (what, ref, f, name)
+        assert ctx.counters()["queue_overflow"] == 0
+        o.close()
