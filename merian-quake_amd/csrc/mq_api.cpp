@@ -1160,8 +1160,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         e = mq_launch_primary(c->scene, c->params, FS[k], guided, c->count_enabled, sub_grid(0), st(k));
         if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
     }
-    if (rounds == 0 || (overlap_pt && S > 1)) { int r = join(); if (r) return r; } // (every chain's first-hit kernel must be done before ev_shaded)
-    if (overlap_pt) { HIPCHK(c, hipEventRecord(c->ev_shaded[parity], s)); c->shaded_valid[parity] = true; }
+    if (rounds == 0) { int r = join(); if (r) return r; }
     if (detail || timed == 0) HIPCHK(c, hipEventRecord(ev[2], s));
     for (int r = 0; r < rounds; r++) {
         for (int k = 0; k < S; k++) {
@@ -1213,6 +1212,9 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         c->volume_outputs_zero = true;
     }
     HIPCHK(c, hipEventRecord(ev[3 + 2 * timed], s));
+    // the first-hit kernel has read this parity's hit buffer (recorded here, at the end of the frame, rather than behind that
+    // kernel: an event between two dependent launches costs ~5 us, and the camera rays that wait for it are two frames away)
+    if (overlap_pt) { HIPCHK(c, hipEventRecord(c->ev_shaded[parity], s)); c->shaded_valid[parity] = true; }
     c->frame_parity++;
     c->ev_rounds[slot] = timed;
     c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
