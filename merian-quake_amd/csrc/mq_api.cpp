@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <random>
 #include <string>
 #include <vector>
@@ -276,6 +277,7 @@ const PropDesc k_props[] = {
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
     {"debug: LC lock statistics", PT_BOOL, POFF(lc_lock_statistics), false, {}},
+    {"LC try-lock", PT_BOOL, POFF(lc_try_lock), false, {}},
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
@@ -387,7 +389,7 @@ void props_to_params(mq_ctx* c) {
     P.gbuffer_hide_sun = q.hide_sun; P.quirk_lc_max_wo_p = q.quirk_lc_max_wo_p; P.quirk_n16_wrap = q.quirk_n16_wrap;
     P.debug_output_selector = q.debug_output_selector;
     P.volume_forward_project = q.volume_forward_project;
-    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning; P.log_learning = q.log_learning; P.lc_lock_protocol = q.lc_lock_statistics; P.debug_output_connected = q.debug_output_connected;
+    P.enable_albedo_mipmap = q.enable_albedo_mipmap; P.enable_emission_mipmap = q.enable_emission_mipmap; P.freeze_learning = q.freeze_learning; P.log_learning = q.log_learning; P.lc_lock_protocol = q.lc_lock_statistics; P.lc_try_lock = q.lc_try_lock; P.debug_output_connected = q.debug_output_connected;
     P.mc_static_inv_width = 1.0f / P.mc_static_grid_width;
     for (uint32_t l = 0; l < MQ_WIDTH_LUT; l++) {
         P.mc_inv_width_lut[l] = 1.0f / grid_width(P.adaptive_grid_type, P.mc_adaptive_grid_steps_per_unit_size, P.mc_adaptive_grid_min_width, P.mc_adaptive_grid_power, l);
@@ -523,6 +525,8 @@ int mq_set_property(mq_ctx* c, const char* key, double value) {
     const PropDesc* d = find_prop(key);
     if (!d) return fail(c, MQ_EUNKNOWN_KEY, std::string("unknown property: ") + key);
     if ((!strcmp(key, "mc samples") || !strcmp(key, "dist mc samples")) && (value < 0 || value > MQ_MAX_MC_SAMPLES)) return fail(c, MQ_EINVAL, std::string(key) + " must be in [0, 30] (render_mcpg.cpp:460,494)");
+    if ((!strcmp(key, "spp") || !strcmp(key, "max path length") || !strcmp(key, "volume spp") || !strcmp(key, "restir: spp")) && (value < 0 || value > 15))
+        return fail(c, MQ_EINVAL, std::string(key) + " must be in [0, 15] (render_mcpg.cpp:487-493, renderer_restir.cpp:268)");
     if (d->type == PT_OPTION) { int nopt = 0; while (nopt < 10 && d->options[nopt]) nopt++; if (value < 0 || value >= nopt) return fail(c, MQ_EINVAL, std::string("option index out of range for ") + key); }
     bool changed = prop_set(c->props, *d, value);
     if (changed) c->params_dirty = true;
@@ -893,7 +897,9 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_counters, sizeof(MqCountersDev)))) return r;
     HIPCHK(c, hipMemset(c->d_counters.p, 0, sizeof(MqCountersDev)));
     c->grid_blocks = std::max(1, c->cu_count) * 8;
-    if ((r = dev_alloc(c, c->d_spill, (size_t)c->subs * c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r; // one region per sub-pipeline
+    // one region per sub-pipeline + one for the camera rays launched on pt_stream: those run BESIDE the previous frame's
+    // kernels (and the ReSTIR / volume passes) on the caller's stream, and a region is indexed by block and thread only
+    if ((r = dev_alloc(c, c->d_spill, (size_t)(c->subs + 1) * c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
     const size_t slots = (size_t)c->tiles_per_rank * 64;
     if ((r = dev_alloc(c, c->d_paths, slots * 112))) return r; // 7 fields of 16 bytes (the volume pass uses 6)
     if ((r = dev_alloc(c, c->d_debug_rng, (size_t)c->W * c->H * 4))) return r;
@@ -1091,7 +1097,6 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     // rounds: every sample needs at most (max_path_length - 1) traced segments, render_mcpg.cpp:142-143
     const int rounds = std::max(0, c->params.spp) * std::max(0, c->params.max_path_length - 1);
     const bool volume = c->params.volume_spp > 0 && u->cam_x[3] > 0.0f; // needs a medium: mu_t > 0
-    if (rounds + (volume ? c->params.volume_spp : 0) > MQ_MAX_ROUNDS) return fail(c, MQ_EINVAL, "spp * (max path length - 1) + volume spp exceeds the round limit of this build");
     const int timed = std::min(rounds, 8); // rounds beyond the 8th are not split out (their time lands in the update interval)
     const int slot = c->ev_slot;
     { int r = drain_slot(c, slot); if (r) return r; } // the slot's previous frame finished long ago
@@ -1146,7 +1151,9 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     const bool packet = c->props.packet_camera_rays && (int)std::max(c->s_depth, c->d_depth) + 2 <= mq_packet_stack_entries();
     if (!c->count_enabled) // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
         for (int k = 0; k < S; k++) {
-            e = mq_launch_primary_trace(c->scene, c->params, FS[k], packet, overlap_pt ? c->grid_frame[3] : sub_grid(3), overlap_pt ? c->pt_stream : st(k));
+            MqFrame FP = FS[k];
+            if (overlap_pt) FP.stack_spill = (unsigned long long*)c->d_spill.p + (size_t)S * c->grid_blocks * mq_render_block_size() * mq_spill_entries(); // pt_stream's own region (its launches run one after the other)
+            e = mq_launch_primary_trace(c->scene, c->params, FP, packet, overlap_pt ? c->grid_frame[3] : sub_grid(3), overlap_pt ? c->pt_stream : st(k));
             if (e) return fail(c, MQ_EHIP, std::string("primary trace launch: ") + hipGetErrorString((hipError_t)e));
         }
     if (overlap_pt) {
@@ -1407,7 +1414,7 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
         F.res_a = spatial ? pong : out; F.res_read = spatial ? out : pong;
         // The generate and shade passes trace one closest-hit ray per pixel and sample: as a wavefront through the MCPG
         // node's queues and traversal kernel ("inline restir rays" = 0, the default), or inline in the pass kernels.
-        const bool wavefront = !q.restir_inline_rays && R.spp + 1 <= MQ_MAX_ROUNDS;
+        const bool wavefront = !q.restir_inline_rays;
         MqFrame FQ;
         if (wavefront) {
             fill_frame(c, u, FQ);
@@ -1663,7 +1670,8 @@ int mq_synth_camera(const mq_ctx* c, uint32_t frame, mq_uniform* u) {
 int mq_load_bsp(mq_ctx* c, const char* bsp_path, const char* palette_path) {
     if (!c || !bsp_path) return MQ_EINVAL;
     std::string err;
-    if (!mq_bsp_load(c, bsp_path, palette_path, err)) return fail(c, MQ_EIO, err);
+    try { if (!mq_bsp_load(c, bsp_path, palette_path, err)) return fail(c, MQ_EIO, err); }
+    catch (const std::exception& e) { return fail(c, MQ_EIO, std::string("map file: ") + e.what()); } // no C++ exception crosses the C ABI
     c->params_dirty = true;
     return MQ_OK;
 }

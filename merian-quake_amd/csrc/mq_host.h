@@ -74,6 +74,7 @@ struct MqProps {
     bool debug_output_connected = false; // the reference derives this from the graph wiring (render_mcpg.cpp:182-183)
     bool freeze_learning = false; // test hook, not a reference property
     bool log_learning = false;    // test hook, not a reference property
+    bool lc_try_lock = false;        // the reference's light-cache try-lock (contended updates cancelled, light_cache.glsl:59-64) instead of the lock-free 8-byte publish
     bool lc_lock_statistics = false; // the reference's light-cache try-lock with per-cell counters + last_update_count per slot (for the state dumps)
     int overlap_camera_rays = 1;      // scheduling of this build: the camera rays of frame n + 1 traced beside kernels of frame n, on a low-priority stream
                                       // with its own hardware queue.  0 off; 2 always: from the start of frame n; 3 update pass: beside frame n's link /

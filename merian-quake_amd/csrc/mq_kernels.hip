@@ -691,18 +691,25 @@ MQ_DEV f3 light_cache_get(const MqParams& P, const mq_uniform& U, const MqLCCell
     light_cache_get_level(P, lc, rng, irr, N, lc_level(P, U, pos), pos, normal);
     return irr;
 }
-// light_cache.glsl:54-84.  The reference takes a per-cell try-lock (atomicExchange of the frame
-// number) and DROPS the update when the lock is contended; this version needs no lock word (see the
-// store below).  Frame 0 cancels every update, as the reference does (its zero-initialised lock
-// word equals params.frame, light_cache.glsl:59-64).
+// light_cache.glsl:54-84.  The reference takes a per-cell try-lock (atomicExchange of the frame number), DROPS the update
+// when the lock is contended and writes the cell's members one by one while it holds the lock.  Here (default) there is no
+// lock word traffic: every writer publishes its result with 8-byte single-copy-atomic stores -- the (irradiance, N) payload
+// in ONE store, a re-keyed cell as two (key first) -- so a cell never holds the halves of two writers' payloads, and of N
+// writers that race on a cell one update survives (the last store) where the reference keeps the first and cancels N - 1:
+// the same number of updates applied, the same N.  "LC try-lock" (and "debug: LC lock statistics", which adds the
+// reference's per-cell counters) runs the reference's protocol itself; measured cost: DESIGN.md section 3.
+// Frame 0 cancels every update, as the reference does (its zero-initialised lock word equals params.frame,
+// light_cache.glsl:59-64).
+typedef unsigned long long mq_u64;
 MQ_DEV void light_cache_update(const MqParams& P, const MqFrame& F, uint32_t& rng, f3 pos, f3 normal, f3 irr, Ctr& ctr) {
     const mq_uniform& U = F.u; MqLCCell* const lc = F.lc;
     uint32_t level = lc_level(P, U, pos), idx, chk;
     lc_address(P, rng, level, pos, normal, idx, chk);
-    if (U.frame == 0u) { ctr.lc_cancel++; if (P.lc_lock_protocol && F.lc_stats) atomicAdd(&F.lc_stats[idx].y, 1u); return; }
+    const bool stats = P.lc_lock_protocol && F.lc_stats;
+    if (U.frame == 0u) { ctr.lc_cancel++; if (stats) atomicAdd(&F.lc_stats[idx].y, 1u); return; }
     MqLCCell* cell = lc + idx;
-    const bool locked = P.lc_lock_protocol && !P.freeze_learning && F.lc_stats; // statistics mode: the reference's try-lock, light_cache.glsl:59-64
-    if (locked && atomicExch(&cell->lock, U.frame) == U.frame) { atomicAdd(&F.lc_stats[idx].y, 1u); ctr.lc_cancel++; return; }
+    const bool locked = (P.lc_try_lock || stats) && !P.freeze_learning; // the reference's try-lock, light_cache.glsl:59-64
+    if (locked && atomicExch(&cell->lock, U.frame) == U.frame) { if (stats) atomicAdd(&F.lc_stats[idx].y, 1u); ctr.lc_cancel++; return; }
     uint4 c = *(const uint4*)cell;
     uint16_t i0 = (uint16_t)(c.z & 0xffffu), i1 = (uint16_t)(c.z >> 16), i2 = (uint16_t)(c.w & 0xffffu);
     f3 cur; uint32_t N;
@@ -718,13 +725,12 @@ MQ_DEV void light_cache_update(const MqParams& P, const MqFrame& F, uint32_t& rn
     const uint32_t nz = o0 | (o1 << 16), nw = o2 | (N << 16);
     if (P.log_learning) learn_log_simple(F, 2u, idx, chk, rekey ? 1u : 0u, nz, nw);
     if (P.freeze_learning) return;
-    // One aligned store publishes the cell: 16 bytes when the cell is (re)keyed, else the 8-byte
-    // (irradiance, N) payload.  Two lanes racing on one cell lose one of the two updates -- the
-    // reference drops contended updates too -- and scattered atomics (about 20 G/s on this chip)
-    // would otherwise bound the kernel.
-    if (rekey) *(uint4*)cell = make_uint4(chk, locked ? U.frame : 0u, nz, nw);
-    else *(uint2*)&cell->irr[0] = make_uint2(nz, nw);
-    if (locked) { atomicAdd(&F.lc_stats[idx].x, 1u); __threadfence(); cell->lock = 0u; } // :82-83
+    // (scattered read-modify-write atomics run at about 20 G/s on this chip; plain 8-byte stores are free of that limit)
+    mq_u64* const c64 = (mq_u64*)__builtin_assume_aligned(cell, 16); // cells are 16-byte records in a hipMalloc'ed table
+    if (rekey) __hip_atomic_store(c64, (mq_u64)chk | ((mq_u64)(locked ? U.frame : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c64 + 1, (mq_u64)nz | ((mq_u64)nw << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stats) atomicAdd(&F.lc_stats[idx].x, 1u);
+    if (locked) { __threadfence(); cell->lock = 0u; } // :82-83
     ctr.lc_ok++;
 }
 
@@ -1016,7 +1022,7 @@ MQ_DEV uint32_t shard_append(uint32_t* tails, bool push) { // returns the interl
     return pos;
 }
 MQ_DEV uint32_t queue_append(const MqFrame& F, int round, bool& push) {
-    uint32_t q = shard_append(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP, push);
+    uint32_t q = shard_append(F.qctrl + MQ_QTAILS(round), push);
     if (push && q >= F.ray_cap) { atomicOr(&F.ctrl[0], 1u); push = false; } // cannot happen with the 2x margin; flagged, never silent
     return q;
 }
@@ -1330,8 +1336,10 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACEQ) void mq_trace_queue_kernel
     uint2* stk = &s_stack[threadIdx.x >> 6][0][lane];
     const uint32_t gid = blockIdx.x * MQ_BLOCK + threadIdx.x;
     unsigned long long* spill = F.stack_spill + (size_t)gid * MQ_SPILL_ENTRIES;
-    const uint32_t* tails = F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP;
-    uint32_t* heads = F.qctrl + MQ_CTRL_HEAD0 + round * MQ_CTRL_GROUP;
+    const uint32_t* tails = F.qctrl + MQ_QTAILS(round);
+    uint32_t* heads = F.qctrl + MQ_QHEADS(round);
+    // the control words of the other round parity: read last by the shading launch before this one, written next by the one behind it
+    if (blockIdx.x == 0 && threadIdx.x < MQ_SHARDS) { F.qctrl[MQ_QTAILS(round + 1) + threadIdx.x * MQ_SHARD_STRIDE] = 0u; F.qctrl[MQ_QHEADS(round + 1) + threadIdx.x * MQ_SHARD_STRIDE] = 0u; }
     Ctr ctr = {};
     const uint32_t wave_id = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
     const uint32_t n_eff = queue_view(tails).n_eff;
@@ -1538,7 +1546,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_bounce_kernel(MqSce
     extern __shared__ uint2 s_dyn[];
     float* lobes = GUIDED ? (float*)(s_dyn + (size_t)(threadIdx.x >> 6) * F.lds_rows2 * 64) + (threadIdx.x & 63) : nullptr;
     const mq_uniform& U = F.u;
-    const QView qv = queue_view(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const QView qv = queue_view(F.qctrl + MQ_QTAILS(round));
     const uint32_t n = qv.n_eff < F.ray_cap ? qv.n_eff : F.ray_cap; // (positions past the buffer were never written, see queue_append)
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
@@ -1827,7 +1835,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_shade_kernel(MqSceneDev sc, MqParams P, MqFrame F, int smp, int round) {
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
-    const QView qv = queue_view(F.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const QView qv = queue_view(F.qctrl + MQ_QTAILS(round));
     const uint32_t n = qv.n_eff < F.ray_cap ? qv.n_eff : F.ray_cap; // (positions past the buffer were never written, see queue_append)
     const uint32_t grid_max_x = F.W / (uint32_t)P.distance_mc_grid_width + 1u;
     const f3 sun_color = F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);

@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <string>
 
 namespace {
 
@@ -92,6 +94,7 @@ bool read_file(const char* path, std::vector<uint8_t>& out) {
 template <class T> bool rd(const std::vector<uint8_t>& f, size_t& at, T& v) { if (at + sizeof(T) > f.size()) return false; memcpy(&v, f.data() + at, sizeof(T)); at += sizeof(T); return true; }
 
 // 8-bit indexed pixels -> RGBA8 texture (+ fullbright mask texture if any texel index >= 224), as the BSP loader does for miptex
+#define MQ_MAX_PICTURE_DIM 4096 // skins and sprite frames: far above anything id Software's formats hold, far below a size_t wrap
 void upload_indexed(mq_ctx* ctx, const uint8_t* px, uint32_t w, uint32_t h, const uint8_t pal[768], bool transparent255, uint32_t texnum, uint32_t* fb_texnum, uint32_t* next_tex) {
     MqHostTex& t = mq_ctx_tex(ctx, texnum); t.w = w; t.h = h; t.flags = MQ_TEX_SRGB | MQ_TEX_MIPMAP; t.px.resize((size_t)w * h * 4);
     bool any_fb = false;
@@ -301,7 +304,7 @@ int mq_dyn_add_brush_model(mq_ctx* ctx, int bsp_model, const float origin[3], co
 int mq_bsp_model_count(const mq_ctx* ctx) { return ctx ? (int)mq_ctx_producers(const_cast<mq_ctx*>(ctx)).bsp_models.size() : 0; }
 
 // ---- id Software MDL ("IDPO", version 6) -> MqAliasModel + skin textures ------------------------------------------
-int mq_load_mdl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* model_out, uint32_t* next_texnum_out) {
+static int load_mdl_impl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* model_out, uint32_t* next_texnum_out) {
     if (!ctx || !path || !model_out) return MQ_EINVAL;
     std::vector<uint8_t> f; std::string err;
     if (!read_file(path, f)) return mq_ctx_fail(ctx, MQ_EIO, std::string("cannot read ") + path);
@@ -311,6 +314,7 @@ int mq_load_mdl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_
     struct Hdr { int32_t ident, version; float scale[3], scale_origin[3], boundingradius, eye[3]; int32_t numskins, skinwidth, skinheight, numverts, numtris, numframes, synctype, flags; float size; } h;
     if (!rd(f, at, h) || h.ident != 0x4f504449 || h.version != 6) return mq_ctx_fail(ctx, MQ_EIO, "not an IDPO version 6 model");
     if (h.numskins < 1 || h.skinwidth < 1 || h.skinheight < 1 || h.numverts < 1 || h.numtris < 1 || h.numframes < 1 || h.numverts > 65535 || h.numtris > 65535) return mq_ctx_fail(ctx, MQ_EIO, "bad model header");
+    if (h.skinwidth > MQ_MAX_PICTURE_DIM || h.skinheight > MQ_MAX_PICTURE_DIM) return mq_ctx_fail(ctx, MQ_EIO, "skin larger than 4096 x 4096"); // (the products below stay far from wrapping size_t)
     MqAliasModel m;
     memcpy(m.scale, h.scale, 12); memcpy(m.scale_origin, h.scale_origin, 12);
     m.skinwidth = (uint32_t)h.skinwidth; m.skinheight = (uint32_t)h.skinheight; m.numverts = (uint32_t)h.numverts;
@@ -319,8 +323,8 @@ int mq_load_mdl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_
     for (int s = 0; s < h.numskins; s++) { // single skins and skin groups (the first picture of a group is used)
         int32_t group; if (!rd(f, at, group)) return mq_ctx_fail(ctx, MQ_EIO, "truncated skins");
         int32_t npics = 1;
-        if (group) { if (!rd(f, at, npics) || npics < 1) return mq_ctx_fail(ctx, MQ_EIO, "bad skin group"); at += 4 * (size_t)npics; }
-        if (at + skin_px * (size_t)npics > f.size()) return mq_ctx_fail(ctx, MQ_EIO, "truncated skin");
+        if (group) { if (!rd(f, at, npics) || npics < 1 || (size_t)npics > f.size() / skin_px) return mq_ctx_fail(ctx, MQ_EIO, "bad skin group"); at += 4 * (size_t)npics; } // (a group cannot hold more pictures than the file has bytes for)
+        if (at > f.size() || skin_px * (size_t)npics > f.size() - at) return mq_ctx_fail(ctx, MQ_EIO, "truncated skin");
         if (next_tex + 2 >= MQ_MAX_GLTEXTURES) return mq_ctx_fail(ctx, MQ_EINVAL, "too many textures");
         const uint32_t tn = next_tex++; uint32_t fb = 0;
         upload_indexed(ctx, f.data() + at, (uint32_t)h.skinwidth, (uint32_t)h.skinheight, pal, false, tn, &fb, &next_tex);
@@ -359,7 +363,7 @@ int mq_load_mdl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_
 }
 
 // ---- id Software SPR ("IDSP", version 1) -> MqSpriteModel + frame textures -------------------------------------------
-int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* model_out, uint32_t* next_texnum_out) {
+static int load_spr_impl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* model_out, uint32_t* next_texnum_out) {
     if (!ctx || !path || !model_out) return MQ_EINVAL;
     std::vector<uint8_t> f; std::string err;
     if (!read_file(path, f)) return mq_ctx_fail(ctx, MQ_EIO, std::string("cannot read ") + path);
@@ -376,7 +380,7 @@ int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_
         if (group) { if (!rd(f, at, n) || n < 1) return mq_ctx_fail(ctx, MQ_EIO, "bad sprite group"); at += 4 * (size_t)n; }
         for (int k = 0; k < n; k++) { // (the first picture of a group is the frame; the others are read past)
             struct Fr { int32_t origin[2], width, height; } fh;
-            if (!rd(f, at, fh) || fh.width < 1 || fh.height < 1 || at + (size_t)fh.width * fh.height > f.size()) return mq_ctx_fail(ctx, MQ_EIO, "truncated sprite frame");
+            if (!rd(f, at, fh) || fh.width < 1 || fh.height < 1 || fh.width > MQ_MAX_PICTURE_DIM || fh.height > MQ_MAX_PICTURE_DIM || (size_t)fh.width * fh.height > f.size() - at) return mq_ctx_fail(ctx, MQ_EIO, "truncated sprite frame");
             if (k == 0) {
                 if (next_tex + 1 >= MQ_MAX_GLTEXTURES) return mq_ctx_fail(ctx, MQ_EINVAL, "too many textures");
                 MqSpriteFrame sf; sf.up = (float)fh.origin[1]; sf.down = (float)((int64_t)fh.origin[1] - fh.height); sf.left = (float)fh.origin[0]; sf.right = (float)((int64_t)fh.width + fh.origin[0]); // (64-bit: the origin of a damaged file may be anything)
@@ -392,6 +396,15 @@ int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_
     *model_out = (int)P.sprites.size() - 1;
     if (next_texnum_out) *next_texnum_out = next_tex;
     return MQ_OK;
+}
+// no C++ exception crosses the C ABI: an allocation a damaged file provokes (std::length_error, std::bad_alloc) is an I/O error
+int mq_load_mdl(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* model_out, uint32_t* next_texnum_out) {
+    try { return load_mdl_impl(ctx, path, palette_path, first_texnum, model_out, next_texnum_out); }
+    catch (const std::exception& e) { return mq_ctx_fail(ctx, MQ_EIO, std::string("model file: ") + e.what()); }
+}
+int mq_load_spr(mq_ctx* ctx, const char* path, const char* palette_path, uint32_t first_texnum, int* model_out, uint32_t* next_texnum_out) {
+    try { return load_spr_impl(ctx, path, palette_path, first_texnum, model_out, next_texnum_out); }
+    catch (const std::exception& e) { return mq_ctx_fail(ctx, MQ_EIO, std::string("sprite file: ") + e.what()); }
 }
 
 } // extern "C"

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_a_k
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_b_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F, MqFrame FQ, int smp) {
     const mq_uniform& U = F.u;
     uint32_t* scratch = (uint32_t*)FQ.paths;
-    const QView qv = queue_view(FQ.qctrl + MQ_CTRL_QUEUE0 + smp * MQ_CTRL_GROUP);
+    const QView qv = queue_view(FQ.qctrl + MQ_QTAILS(smp));
     const uint32_t n = qv.n_eff < FQ.ray_cap ? qv.n_eff : FQ.ray_cap, stride = gridDim.x * blockDim.x;
     for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
         const uint32_t q = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_a_kern
 }
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_b_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F, MqFrame FQ, int round) {
     const mq_uniform& U = F.u;
-    const QView qv = queue_view(FQ.qctrl + MQ_CTRL_QUEUE0 + round * MQ_CTRL_GROUP);
+    const QView qv = queue_view(FQ.qctrl + MQ_QTAILS(round));
     const uint32_t n = qv.n_eff < FQ.ray_cap ? qv.n_eff : FQ.ray_cap, stride = gridDim.x * blockDim.x;
     for (uint32_t it = 0; it < (n + stride - 1) / stride; it++) {
         const uint32_t q = it * stride + blockIdx.x * blockDim.x + threadIdx.x;

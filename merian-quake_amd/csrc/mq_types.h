@@ -29,12 +29,17 @@
 // shard s of a queue owns every 16th block of 64 positions.
 #define MQ_SHARDS 16
 #define MQ_SHARD_STRIDE 32                                  // words between the counters of two shards (128 B)
-#define MQ_MAX_ROUNDS 30
 #define MQ_CTRL_GROUP (MQ_SHARDS * MQ_SHARD_STRIDE)         // words of one sharded counter
 #define MQ_CTRL_UPDATES MQ_CTRL_GROUP                       // update-queue tails (group 1; group 0 holds the overflow flag)
-#define MQ_CTRL_QUEUE0 (2 * MQ_CTRL_GROUP)                  // ray-queue tails, one group per round
-#define MQ_CTRL_HEAD0 (MQ_CTRL_QUEUE0 + (MQ_MAX_ROUNDS + 1) * MQ_CTRL_GROUP) // traversal fetch heads (64-entry blocks), one group per round
-#define MQ_CTRL_WORDS (MQ_CTRL_HEAD0 + (MQ_MAX_ROUNDS + 1) * MQ_CTRL_GROUP)
+// Ray queues: rounds run one after the other (round r's queue is filled by the shading launch of round r - 1 and drained by
+// the trace + shading launches of round r), so TWO sets of control words alternate by round parity, however many rounds a
+// frame has (spp, max path length and volume spp go up to 15 each, render_mcpg.cpp:487-493): the trace launch of round r,
+// which runs between the last reader of round r - 1's words and the first writer of round r + 1's, zeroes the other set.
+#define MQ_CTRL_QUEUE0 (2 * MQ_CTRL_GROUP)                  // ray-queue tails, one group per round parity
+#define MQ_CTRL_HEAD0 (MQ_CTRL_QUEUE0 + 2 * MQ_CTRL_GROUP)  // traversal fetch heads (64-entry blocks), one group per round parity
+#define MQ_CTRL_WORDS (MQ_CTRL_HEAD0 + 2 * MQ_CTRL_GROUP)
+#define MQ_QTAILS(round) (MQ_CTRL_QUEUE0 + ((round) & 1) * MQ_CTRL_GROUP)
+#define MQ_QHEADS(round) (MQ_CTRL_HEAD0 + ((round) & 1) * MQ_CTRL_GROUP)
 
 // 80-byte compressed 8-wide BVH node (Ylitie et al. 2017 layout).
 struct MqNode {
@@ -147,6 +152,7 @@ struct MqParams {
     int32_t debug_output_connected; // DEBUG_OUTPUT_CONNECTED, render_mcpg.cpp:182-183 (selector: debug_output_selector above)
     int32_t freeze_learning; // test hook: every learning computation and RNG draw runs, the stores to MC / LC / distance state do not
     int32_t lc_lock_protocol; // "debug: LC lock statistics": the reference's per-cell try-lock (light_cache.glsl:59-64,82-83) with its success / cancel counters
+    int32_t lc_try_lock;      // "LC try-lock": the try-lock alone (contended updates are cancelled as in the reference), no counters
     int32_t log_learning;    // test hook: every PROPOSED learning write is appended to MqFrame::learn_log (layouts: include/mq.h, mq_debug_learn_log_read)
     // derived on the host with the same float operations the kernels would use (mq_api.cpp props_to_params)
     float mc_static_inv_width;

@@ -223,6 +223,10 @@ def test_oracle_bvh_equals_brute_force(gpu_ctx):
     # every material class (liquid warps, teleporter / waterfall / sprite emission, solid particle colours, alias-style
     # triangles, vertex alpha below and above the threshold, texture alpha, liquids in the alpha-tested set) in fog
     ("synth_materials", 224, 160, {"spp": 2, "max path length": 4}),
+    # the top of the reference's ranges (render_mcpg.cpp:487-493): 36 and 210 rounds of trace + shade per frame (the ray
+    # queues' control words alternate by round parity: no round limit)
+    ("synth_start", 128, 80, {"spp": 4, "max path length": 10}),
+    ("synth_tiny", 64, 48, {"spp": 15, "max path length": 15}),
 ])
 def test_reference_mode_frame_parity(gpu_ctx, scene, W, H, props):
     """Deterministic (unguided) frame: every output of both nodes matches the oracle.
@@ -515,7 +519,8 @@ def _copy_learned_state(ctx, o, with_distance=False):
     return gmc, glc
 
 
-VOLUME_VARIANTS = [{"volume: use LC": 0}, {"Phase Prob": 0.9}, {"dist guide p": 0.1}, {"volume spp": 4, "particle size": 3.0}, {"dist mc grid width": 10, "dist mc states per vertex": 4}]
+VOLUME_VARIANTS = [{"volume: use LC": 0}, {"Phase Prob": 0.9}, {"dist guide p": 0.1}, {"volume spp": 4, "particle size": 3.0}, {"dist mc grid width": 10, "dist mc states per vertex": 4},
+                   {"volume spp": 15, "spp": 3, "max path length": 7}]  # 18 surface + 15 volume rounds
 
 
 @pytest.mark.parametrize("variant", VOLUME_VARIANTS, ids=[",".join("%s=%s" % kv for kv in v.items()) for v in VOLUME_VARIANTS])
@@ -598,6 +603,7 @@ def test_debug_views_match_oracle(gpu_ctx):
 GUIDED_VARIANTS = [
     {"max path length": 2}, {"max path length": 5, "spp": 1}, {"surf: use LC": 0}, {"adaptive grid type": "quadratic", "LC grid type": "quadratic"},
     {"mc fast recovery": 0}, {"adaptive grid prob": 0.0}, {"adaptive grid prob": 1.0}, {"BSDF Prob": 0.9}, {"ML Prior": 3.0, "quirk: LC max(wo_p,10)": 0},
+    {"spp": 4, "max path length": 10},  # 36 rounds: a legal reference configuration that round 2's 30-round cap refused
 ]
 
 

@@ -216,3 +216,74 @@ c.close()
     assert r.returncode == 0, r.stderr[-1500:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     assert int(line[1]) & 1 and line[2] == "True" and line[3] == "True", line
+
+
+def _chain_uniform(frame, mu_t):
+    """Camera at the near end of tests/deep_scene.py's chain, looking down the axis of the frames; a little fog."""
+    import mqhip
+    u = mqhip.Uniform()
+    x = 0.25 + 0.002 * frame
+    for k, v in enumerate((x, 0.0, 0.0, mu_t)):
+        u.cam_x[k] = v
+    for k, v in enumerate((1.0, 0.0, 0.0, 1.0 / 60.0)):
+        u.cam_w[k] = v
+    for k, v in enumerate((0.0, 0.0, 1.0, 0.0)):
+        u.cam_u[k] = v
+    px = 0.25 + 0.002 * max(frame - 1, 0)
+    for k, v in enumerate((px, 0.0, 0.0, 0.5 * mu_t)):
+        u.prev_cam_x[k] = v
+    for k, v in enumerate((1.0, 0.0, 0.0, 0.5 * mu_t)):
+        u.prev_cam_w[k] = v
+    for k, v in enumerate((0.0, 0.0, 1.0, 0.5 * mu_t)):
+        u.prev_cam_u[k] = v
+    u.sky_rt_bk = 0xffffffff; u.sky_lf_ft = 0xffffffff; u.sky_up_dn = 0xffffffff
+    u.cl_time = frame / 60.0; u.frame = frame
+    return u
+
+
+def test_deep_traversal_stacks_with_overlapped_camera_rays(mqlib):
+    """the camera rays of frame n + 1 run on their own stream BESIDE frame n's bounce, volume and ReSTIR
+    kernels; every one of those spills the part of a traversal stack beyond its 12 LDS entries to a global area indexed by
+    block and thread.  The launches on the side stream now have their own area.  A scene whose central rays need 15 - 16
+    stack entries (tests/deep_scene.py proves it on the host), with the per-frame tree, volume passes and the ReSTIR node
+    on: outputs with the overlap off == outputs with the overlap from the start of the previous frame."""
+    import mqhip
+    import deep_scene
+
+    def run(overlap):
+        c = mqhip.Context(0)
+        c.header_defaults()
+        vtx, idx, ext = deep_scene.chain_scene(80, 1.6)
+        c.set_geometry(0, vtx, None, idx, ext, mqhip.MQ_GEO_OPAQUE | mqhip.MQ_GEO_STATIC)
+        tex = np.full((8, 8, 4), 200, np.uint8)
+        c.set_texture(1, tex, mqhip.MQ_TEX_SRGB)
+        c.set_constants((4.0, 4.0, 4.0), (0.57735026919, 0.57735026919, 0.57735026919))
+        for k, v in {"randomize seed": 0, "seed": 0x5EED, **SMALL, "reference mode": 1, "spp": 2, "max path length": 3, "volume spp": 2, "particle size": 7.0,
+                     "volume: use LC": 0, "mc samples": 0, "dist mc samples": 0, "volume forward project": 0, "overlap camera rays": overlap,
+                     "restir: randomize seed": 0, "restir: spp": 1, "restir: enable temporal reuse": 1, "restir: spatial reuse iterations": 2,
+                     "restir: temporal bias correction": "raytraced", "restir: spatial bias correction": "raytraced", "inline restir rays": 1}.items():
+            c.set_property(k, v)
+        outs = []
+        # a per-frame triangle in front of the camera: the per-frame tree's root waits at the bottom of every stack (+1 entry).
+        # Committed ONCE: a commit waits for the frames in flight, and the point here is that the host runs ahead.
+        tri = np.array([[3.0, -0.2, -0.2], [3.0, 0.2, -0.2], [3.0, 0.0, 0.2]], np.float32)
+        c.set_geometry(5, tri, tri - np.float32(0.01), np.array([[0, 2, 1]], np.uint32), ext[:1], mqhip.MQ_GEO_OPAQUE)
+        c.commit()
+        nodes, _ = c.get_bvh()
+        depth, _ = deep_scene.emulate_stack_depth(nodes, [0.25, 0, 0], [1, 0, 0], start_sp=1)
+        assert depth >= 14, "the scene no longer overflows the 12 LDS stack entries (%d)" % depth
+        c.connect(256, 160)
+        for f in range(6):
+            u = _chain_uniform(f, 1e-3)
+            c.process(u)
+            c.restir_process(u)
+        for which in (mqhip.OUT_IRRADIANCE, mqhip.OUT_VOLUME, mqhip.OUT_HITS, mqhip.OUT_RESTIR_IRRADIANCE, mqhip.OUT_RESTIR_RESERVOIRS):
+            outs.append(c.read_output(which).copy())
+        assert c.counters()["queue_overflow"] == 0
+        c.close()
+        return outs
+
+    a, b = run("off"), run("always")
+    assert a[0].view(np.float32).sum() > 0 and np.isfinite(a[0].view(np.float32)).all()
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
