@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--reference-mode", type=int, default=0)
     ap.add_argument("--volume-spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prop", action="append", default=[], metavar="KEY=VALUE", help="set a renderer property away from the workload's (A/B experiments: the line then names it)")
     ap.add_argument("--bsp", default=None, help="a user-supplied BSP29 / BSP2 map instead of the synthetic stand-in (camera at the player start); "
                     "default: $MQ_QUAKE_DIR/id1/maps/<--map>.bsp if that file exists")
     ap.add_argument("--map", default="ad_sepulcher")
@@ -195,6 +196,14 @@ def main():
     ctx.json_defaults()
     props = {"randomize seed": 0, "seed": 0x5EED, "spp": args.spp, "max path length": 3, "reference mode": args.reference_mode,
              "volume spp": args.volume_spp}  # config 3 has no volumes; config 4 (synth_tears, fog) renders them
+    extra = {}
+    for kv in args.prop:
+        k, _, v = kv.partition("=")
+        try:
+            extra[k] = float(v)
+        except ValueError:
+            extra[k] = v
+    props.update(extra)
     for k, v in props.items():
         ctx.set_property(k, v)
     bsp = args.bsp
@@ -349,7 +358,7 @@ def main():
     # the update pass ("overlap camera rays"), so the surface-pass interval alone no longer holds all of a frame's work.
     frame_ms = (render_sum + update_sum) / n_timed
     default_workload = (world == 1 and not selftest and (W, H) == (1920, 1080) and args.scene == "synth_sepulcher" and args.scene_seed == 2
-                        and args.spp == 1 and not args.reference_mode and args.volume_spp == 0)
+                        and args.spp == 1 and not args.reference_mode and args.volume_spp == 0 and not extra)
     traffic, traffic_src = pmc_traffic(dom, default_workload, learn, args.steps)
     # `achieved` / `frac`: ALGORITHMIC bytes of the dominant kernel per launch over its measured launch time (the contract's
     # definition).  `traffic` is what the HBM actually moved per launch (PMC); `hbm_measured` prices that against the peak:
@@ -376,7 +385,7 @@ def main():
            "config": {"workload": "%s, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
                                   % ("user-supplied map %s, camera at the player start" % args.scene if bsp else "%s(seed=%d) stand-in for ad_sepulcher" % (args.scene, args.scene_seed),
                                      W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
-                      "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world, "ranks": world, "backend": (dist.get_backend() if exchange else "none"),
+                      **({"properties_changed": extra} if extra else {}), "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world, "ranks": world, "backend": (dist.get_backend() if exchange else "none"),
                       "collective": "none" if not exchange else "%dx RCCL all_gather of %d B/rank per frame%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "")},
            "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

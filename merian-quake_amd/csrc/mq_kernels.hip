@@ -701,6 +701,19 @@ MQ_DEV f3 light_cache_get(const MqParams& P, const mq_uniform& U, const MqLCCell
 // Frame 0 cancels every update, as the reference does (its zero-initialised lock word equals params.frame,
 // light_cache.glsl:59-64).
 typedef unsigned long long mq_u64;
+// Scope of the publishing stores.  An AGENT-scope atomic store is a write-through on this multi-die part (global_store ... sc1:
+// the per-die L2s are not coherent with each other inside a kernel) and cost +0.22 ms per 1080p frame in the terminal shading
+// launches; a WORKGROUP-scope atomic store is the same single 8-byte store instruction without the write-through -- the
+// non-tearing property is the instruction's, the visibility to other dies is that of every other store of these kernels
+// (the tables are read "eventually": the reference races on them too).  profiles/r03_b_lc_publish.txt
+#ifndef MQ_LC_PUBLISH
+#define MQ_LC_PUBLISH 1
+#endif
+#if MQ_LC_PUBLISH == 0
+#define MQ_LC_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
+#define MQ_LC_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 MQ_DEV void light_cache_update(const MqParams& P, const MqFrame& F, uint32_t& rng, f3 pos, f3 normal, f3 irr, Ctr& ctr) {
     const mq_uniform& U = F.u; MqLCCell* const lc = F.lc;
     uint32_t level = lc_level(P, U, pos), idx, chk;
@@ -727,8 +740,13 @@ MQ_DEV void light_cache_update(const MqParams& P, const MqFrame& F, uint32_t& rn
     if (P.freeze_learning) return;
     // (scattered read-modify-write atomics run at about 20 G/s on this chip; plain 8-byte stores are free of that limit)
     mq_u64* const c64 = (mq_u64*)__builtin_assume_aligned(cell, 16); // cells are 16-byte records in a hipMalloc'ed table
-    if (rekey) __hip_atomic_store(c64, (mq_u64)chk | ((mq_u64)(locked ? U.frame : 0u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(c64 + 1, (mq_u64)nz | ((mq_u64)nw << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if MQ_LC_PUBLISH == 2 // round 2's publish, kept for the A/B: one 16-byte store for a re-keyed cell -- tears at dword granularity
+    if (rekey) *(uint4*)cell = make_uint4(chk, locked ? U.frame : 0u, nz, nw);
+    else *(uint2*)&cell->irr[0] = make_uint2(nz, nw);
+#else
+    if (rekey) __hip_atomic_store(c64, (mq_u64)chk | ((mq_u64)(locked ? U.frame : 0u) << 32), __ATOMIC_RELAXED, MQ_LC_SCOPE);
+    __hip_atomic_store(c64 + 1, (mq_u64)nz | ((mq_u64)nw << 32), __ATOMIC_RELAXED, MQ_LC_SCOPE);
+#endif
     if (stats) atomicAdd(&F.lc_stats[idx].x, 1u);
     if (locked) { __threadfence(); cell->lock = 0u; } // :82-83
     ctr.lc_ok++;
