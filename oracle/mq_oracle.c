@@ -112,6 +112,8 @@ struct orc_ctx {
     float post_par[2][6];
     float* post_out[2]; float* post_hist[2]; float* post_prev_out[2]; float* post_prev_hist[2]; gbuf_t* post_prev_gb; float* post_final;
     int post_first; int volume_ran;
+    struct orc_pool* pool; /* persistent worker threads of the multi-threaded passes */
+    int parallel_update;   /* orc_process_mt flag: the update pass over the workers too (racy, like the reference's dispatch) */
 };
 
 /* ---------------------------------------------------------------- params */
@@ -161,6 +163,7 @@ orc_ctx* orc_create(const orc_params_t* p) {
     }
     return c;
 }
+static void pool_destroy(orc_ctx* c);
 static void free_state(orc_ctx* c) {
     for (int k = 0; k < 2; k++) { free(c->post_out[k]); free(c->post_hist[k]); free(c->post_prev_out[k]); free(c->post_prev_hist[k]); c->post_out[k] = c->post_hist[k] = c->post_prev_out[k] = c->post_prev_hist[k] = NULL; }
     free(c->post_prev_gb); free(c->post_final); c->post_prev_gb = NULL; c->post_final = NULL;
@@ -176,6 +179,7 @@ static void free_state(orc_ctx* c) {
 }
 void orc_destroy(orc_ctx* c) {
     if (!c) return;
+    pool_destroy(c);
     for (int i = 0; i < MAX_GEOMETRIES; i++) { free(c->geo[i].vtx); free(c->geo[i].prev_vtx); free(c->geo[i].idx); free(c->geo[i].ext); }
     for (int i = 0; i < MAX_GLTEXTURES; i++) { free(c->tex[i].px); free(c->tex[i].mip); }
     free(c->tex); free(c->tris); free(c->nodes);
@@ -1355,35 +1359,106 @@ static void volume_pixel(tls_t* tl, uint32_t px, uint32_t py) {
 
 /* ---------------------------------------------------------------- frame driver */
 
-typedef struct { orc_ctx* c; int tid, nthreads, pass; orc_counters_t ctr; } job_t;
-static void* worker(void* arg) {
-    job_t* j = (job_t*)arg; orc_ctx* c = j->c;
+/* Worker pool: threads are created once per context and woken per pass (they used to be created and joined three times per
+ * frame); rows -- and, with the parallel-update flag, update slots -- are claimed from a shared counter, so a thread
+ * that drew cheap rows (sky) takes more of them.  Which thread renders a pixel never changes what the pixel computes. */
+typedef struct orc_pool {
+    pthread_mutex_t m; pthread_cond_t go, done;
+    int n, active, pending, stop, pass; uint64_t gen;
+    pthread_t th[256]; struct pool_arg { struct orc_pool* pool; int tid; } arg[256]; orc_counters_t ctr[256];
+    orc_ctx* c; uint32_t next, upd_n;
+} orc_pool;
+static void pool_work(orc_pool* P, int tid) {
+    orc_ctx* c = P->c;
     tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
-    for (uint32_t y = (uint32_t)j->tid; y < c->H; y += (uint32_t)j->nthreads)
-        for (uint32_t x = 0; x < c->W; x++) { if (j->pass == 0) gbuffer_pixel(&tl, x, y); else if (j->pass == 1) mcpg_pixel(&tl, x, y); else volume_pixel(&tl, x, y); }
-    j->ctr = tl.ctr;
-    return NULL;
+    if (P->pass == 3) { /* update pass: chunks of touched slots */
+        for (;;) {
+            uint32_t i0 = __atomic_fetch_add(&P->next, 64u, __ATOMIC_RELAXED);
+            if (i0 >= P->upd_n) break;
+            uint32_t i1 = i0 + 64u < P->upd_n ? i0 + 64u : P->upd_n;
+            for (uint32_t i = i0; i < i1; i++) apply_slot(&tl, c->upd_touched[i]);
+        }
+    } else for (;;) {
+        uint32_t y = __atomic_fetch_add(&P->next, 1u, __ATOMIC_RELAXED);
+        if (y >= c->H) break;
+        for (uint32_t x = 0; x < c->W; x++) { if (P->pass == 0) gbuffer_pixel(&tl, x, y); else if (P->pass == 1) mcpg_pixel(&tl, x, y); else volume_pixel(&tl, x, y); }
+    }
+    P->ctr[tid] = tl.ctr;
+}
+static void* pool_thread(void* arg) {
+    orc_pool* P = ((struct pool_arg*)arg)->pool;
+    const int tid = ((struct pool_arg*)arg)->tid;
+    uint64_t seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&P->m);
+        while (P->gen == seen && !P->stop) pthread_cond_wait(&P->go, &P->m);
+        if (P->stop) { pthread_mutex_unlock(&P->m); return NULL; }
+        seen = P->gen;
+        const int work = tid < P->active;
+        pthread_mutex_unlock(&P->m);
+        if (work) pool_work(P, tid);
+        pthread_mutex_lock(&P->m);
+        if (--P->pending == 0) pthread_cond_signal(&P->done);
+        pthread_mutex_unlock(&P->m);
+    }
+}
+static void pool_destroy(orc_ctx* c) {
+    orc_pool* P = c->pool;
+    if (!P) return;
+    pthread_mutex_lock(&P->m); P->stop = 1; pthread_cond_broadcast(&P->go); pthread_mutex_unlock(&P->m);
+    for (int i = 0; i < P->n; i++) pthread_join(P->th[i], NULL);
+    pthread_mutex_destroy(&P->m); pthread_cond_destroy(&P->go); pthread_cond_destroy(&P->done);
+    free(P); c->pool = NULL;
+}
+static orc_pool* pool_get(orc_ctx* c, int threads) {
+    if (c->pool && c->pool->n >= threads) return c->pool;
+    pool_destroy(c);
+    orc_pool* P = (orc_pool*)calloc(1, sizeof *P);
+    if (!P) return NULL;
+    pthread_mutex_init(&P->m, NULL); pthread_cond_init(&P->go, NULL); pthread_cond_init(&P->done, NULL);
+    P->c = c;
+    for (int i = 0; i < threads; i++) { P->arg[i].pool = P; P->arg[i].tid = i; if (pthread_create(&P->th[i], NULL, pool_thread, &P->arg[i]) != 0) break; P->n++; }
+    c->pool = P;
+    return P;
 }
 static void acc_ctr(orc_counters_t* a, const orc_counters_t* b) {
     a->rays += b->rays; a->nodes += b->nodes; a->tris += b->tris; a->segments += b->segments; a->guided_segments += b->guided_segments;
     a->lc_touches += b->lc_touches; a->mc_updates_accepted += b->mc_updates_accepted; a->mc_updates_dropped += b->mc_updates_dropped; a->mc_state_reads += b->mc_state_reads;
 }
+static void pool_run(orc_ctx* c, int pass, int threads, uint32_t upd_n) {
+    orc_pool* P = pool_get(c, threads);
+    if (!P || P->n < 1) return;
+    pthread_mutex_lock(&P->m);
+    P->pass = pass; P->next = 0; P->upd_n = upd_n; P->active = threads < P->n ? threads : P->n; P->pending = P->n;
+    memset(P->ctr, 0, sizeof P->ctr);
+    P->gen++;
+    pthread_cond_broadcast(&P->go);
+    while (P->pending) pthread_cond_wait(&P->done, &P->m);
+    pthread_mutex_unlock(&P->m);
+    for (int i = 0; i < P->active; i++) acc_ctr(&c->ctr, &P->ctr[i]);
+}
 static void run_pass(orc_ctx* c, int pass, int threads) {
     if (threads < 1) threads = 1; if (threads > 256) threads = 256;
-    job_t jobs[256]; pthread_t th[256];
-    for (int i = 0; i < threads; i++) { jobs[i].c = c; jobs[i].tid = i; jobs[i].nthreads = threads; jobs[i].pass = pass; memset(&jobs[i].ctr, 0, sizeof(orc_counters_t)); }
-    if (threads == 1) worker(&jobs[0]);
-    else { for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, &jobs[i]); for (int i = 0; i < threads; i++) pthread_join(th[i], NULL); }
-    for (int i = 0; i < threads; i++) acc_ctr(&c->ctr, &jobs[i].ctr);
+    if (threads == 1) { /* the calling thread, rows in order: the sequential frames the tests' learning runs rely on */
+        tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
+        for (uint32_t y = 0; y < c->H; y++)
+            for (uint32_t x = 0; x < c->W; x++) { if (pass == 0) gbuffer_pixel(&tl, x, y); else if (pass == 1) mcpg_pixel(&tl, x, y); else volume_pixel(&tl, x, y); }
+        acc_ctr(&c->ctr, &tl.ctr);
+    } else pool_run(c, pass, threads, 0);
 }
 
-/* update pass, render_mcpg.cpp:270-277: every touched slot, ascending slot order */
-static void run_update_pass(orc_ctx* c) {
+/* update pass, render_mcpg.cpp:270-277: every touched slot, ascending slot order (one thread: deterministic); with
+ * orc_process_mt's parallel-update flag the slots are spread over the workers -- compute_updates.comp is one GPU thread per
+ * slot, unordered -- which is what bench.py's CPU baseline times */
+static void run_update_pass(orc_ctx* c, int threads) {
     uint32_t n = c->upd_pool_used < c->upd_pool_cap ? c->upd_pool_used : c->upd_pool_cap;
-    qsort(c->upd_touched, n, 4, cmp_u32);
-    tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
-    for (uint32_t i = 0; i < n; i++) apply_slot(&tl, c->upd_touched[i]);
-    acc_ctr(&c->ctr, &tl.ctr);
+    if (c->parallel_update && threads > 1 && n > 4096u) pool_run(c, 3, threads > 256 ? 256 : threads, n);
+    else {
+        qsort(c->upd_touched, n, 4, cmp_u32);
+        tls_t tl; memset(&tl, 0, sizeof tl); tl.c = c;
+        for (uint32_t i = 0; i < n; i++) apply_slot(&tl, c->upd_touched[i]);
+        acc_ctr(&c->ctr, &tl.ctr);
+    }
     c->upd_pool_used = 0;
 }
 
@@ -1416,7 +1491,7 @@ int orc_debug_apply_updates(orc_ctx* c, const uint32_t* records, size_t n, const
         c->upd_count[slot]++;
     }
     c->touch = touches; c->touch_cap = touches ? touch_cap : 0; c->touch_n = 0;
-    run_update_pass(c);
+    run_update_pass(c, 1);
     if (n_touches) *n_touches = c->touch_n;
     c->touch = NULL; c->touch_cap = c->touch_n = 0;
     return 0;
@@ -1433,7 +1508,7 @@ int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
     }
     run_pass(c, 0, threads);
     run_pass(c, 1, threads);
-    run_update_pass(c);
+    run_update_pass(c, threads);
     /* volume passes, render_mcpg.cpp:280-320: copy mv, forward-project, single-scatter estimator.
      * Its Markov-chain updates stay queued until the next frame's update pass. */
     if (c->p.volume_spp > 0) {
@@ -1447,6 +1522,13 @@ int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads) {
     } else { memset(c->volume, 0, px * 16); c->volume_ran = 0; }
     c->iteration++;
     return 0;
+}
+
+int orc_process_mt(orc_ctx* c, const orc_uniform_t* u, int render, int threads, int parallel_update) {
+    c->parallel_update = parallel_update;
+    const int r = orc_process(c, u, render, threads);
+    c->parallel_update = 0;
+    return r;
 }
 
 /* ---------------------------------------------------------------- ReSTIR DI node */

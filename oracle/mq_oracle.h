@@ -144,6 +144,9 @@ int orc_connect(orc_ctx* c, uint32_t w, uint32_t h);
 /* one frame: g-buffer pass, surface pass, update pass (render_mcpg.cpp:243-277).
  * threads > 1 is only deterministic in reference mode. */
 int orc_process(orc_ctx* c, const orc_uniform_t* u, int render, int threads);
+/* the same with the update pass spread over the worker threads too (unordered, as the reference's one-thread-per-slot dispatch):
+ * the CPU baseline of bench.py; tests use orc_process, whose update pass is sequential and deterministic */
+int orc_process_mt(orc_ctx* c, const orc_uniform_t* u, int render, int threads, int parallel_update);
 const void* orc_output(orc_ctx* c, int which, size_t* bytes);
 void orc_get_counters(orc_ctx* c, orc_counters_t* out, int reset);
 /* learning state, oracle layout: which 0 = Markov chains (52 B: id u32, 3 unused f32, w_tgt f32x3, sum_w, w_cos, mv f16x3,

@@ -86,6 +86,7 @@ def lib():
         l.orc_commit.argtypes = [P, C.c_int]
         l.orc_connect.argtypes = [P, C.c_uint32, C.c_uint32]
         l.orc_process.argtypes = [P, P, C.c_int, C.c_int]
+        l.orc_process_mt.argtypes = [P, P, C.c_int, C.c_int, C.c_int]
         l.orc_output.restype = P
         l.orc_output.argtypes = [P, C.c_int, C.POINTER(C.c_size_t)]
         l.orc_get_counters.argtypes = [P, C.POINTER(Counters), C.c_int]
@@ -169,8 +170,12 @@ class Oracle:
         assert self.l.orc_connect(self.h, w, h) == 0
         self.W, self.H = w, h
 
-    def process(self, uniform, render=True, threads=1):
-        assert self.l.orc_process(self.h, C.addressof(uniform), 1 if render else 0, threads) == 0
+    def process(self, uniform, render=True, threads=1, parallel_update=False):
+        """parallel_update: the update pass over the worker threads too (unordered, like the reference's dispatch): the CPU baseline only"""
+        if parallel_update:
+            assert self.l.orc_process_mt(self.h, C.addressof(uniform), 1 if render else 0, threads, 1) == 0
+        else:
+            assert self.l.orc_process(self.h, C.addressof(uniform), 1 if render else 0, threads) == 0
 
     def output(self, which):
         n = C.c_size_t()
