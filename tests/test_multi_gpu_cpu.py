@@ -74,8 +74,10 @@ def test_bench_gpus_n_launches_n_ranks_itself(monkeypatch, capsys):
     bench = importlib.import_module("bench")
     seen = {}
 
-    def fake_run(cmd, env=None, stdout=None, text=None):
-        seen["cmd"], seen["env"] = cmd, env
+    def fake_run(cmd, env=None, stdout=None, text=None, timeout=None):
+        seen["cmd"], seen["env"], seen["timeout"] = cmd, env, timeout
+        if seen.get("hang"):
+            raise subprocess.TimeoutExpired(cmd, timeout)
         class R:
             returncode = 0
         R.stdout = "noise from a rank\n" + json.dumps({"metric": "m", "n_gpus": seen["n"]}) + "\n"
@@ -91,9 +93,14 @@ def test_bench_gpus_n_launches_n_ranks_itself(monkeypatch, capsys):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["timeout"] and seen["timeout"] > 0  # the child run is bounded ...
     seen["n"] = 1  # a run that silently rendered on one rank must not pass for a 4-rank result
     with pytest.raises(SystemExit):
         bench.main()
+    seen["n"], seen["hang"] = 4, True  # ... and a run that does not come back is a failure, not a hang
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "did not finish" in str(e.value)
 
 
 def test_bench_launcher_fails_when_a_rank_fails():
