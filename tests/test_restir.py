@@ -136,3 +136,50 @@ def test_config5_azad_4k_restir_plus_mcpg(gpu_ctx):
         compare(ctx, o, "config 5 frame %d" % f)
     total = ctx.irradiance()[..., :3] + ctx.image(mqhip.OUT_RESTIR_IRRADIANCE)[..., :3]
     assert np.isfinite(total).all() and total.sum() > 0
+
+
+@pytest.mark.gpu
+def test_config5_azad_4k_restir_plus_guided_mcpg(gpu_ctx):
+    """BASELINE config 5 AS STATED: synth_azad(seed=4) 3840x2160, ReSTIR DI (temporal + spatial reuse) combined with the
+    GUIDED MCPG pass.  The guided estimator is deterministic from a given learning state ("debug: freeze learning"): the oracle
+    learns at 160x90 (its tables are addressed by world-space hash grids), both sides get that state at full size, and the
+    next frames must be bit-identical in the MCPG radiance, the ReSTIR radiance, moments and all 64 bytes of every reservoir."""
+    import mqhip
+    from test_gpu_parity import _copy_learned_state
+    ctx = gpu_ctx
+    W, H = 3840, 2160
+    props = {"reference mode": 0, "spp": 1, "max path length": 3, "restir: spp": 1, "restir: enable temporal reuse": 1, "restir: spatial reuse iterations": 1,
+             "adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16}
+    o = setup(ctx, "synth_azad", 4, props, 160, 90)
+    for f in range(4):
+        o.process(ctx.synth_camera(36 + f), threads=1)
+    omc, olc = o.state(0).copy(), o.state(1).copy()
+    assert (omc["sum_w"] > 0).sum() > 1000 and (olc["N"] > 0).sum() > 1000
+    ctx.set_property("debug: freeze learning", 1)
+    try:
+        ctx.connect(W, H); o.connect(W, H)
+        o.set_params(orc.params_from_ctx(ctx, ctx.get_constants()))
+        rp = orc.restir_params_from_ctx(ctx)
+        u = ctx.synth_camera(39)
+        ctx.process(u); ctx.restir_process(u)            # the first frame after a connect zeroes the tables on both sides
+        o.process(u, threads=TH); o.restir_process(rp, u, threads=TH)
+        o.state(0)[:] = omc; o.state(1)[:] = olc
+        _copy_learned_state(ctx, o)
+        ctx.enable_counters(True)
+        for f in (40, 41):
+            u = ctx.synth_camera(f)
+            o.counters(reset=True)
+            ctx.process(u); ctx.restir_process(u)
+            o.process(u, threads=TH); o.restir_process(rp, u, threads=TH)
+            cg, co = ctx.counters(), o.counters()
+            assert cg["guided_segments"] == co["guided_segments"] > 1000000 and cg["mc_state_reads"] == co["mc_state_reads"]
+            bad = (ctx.irradiance().view(np.uint32) != o.irradiance().view(np.uint32)).any(-1)
+            assert not bad.any(), "frame %d: %d MCPG pixels differ, first %r" % (f, bad.sum(), np.argwhere(bad)[0])
+            compare(ctx, o, "config 5 guided, frame %d" % f)
+        assert o.restir_output(2)["M"].max() > 1  # temporal + spatial reuse merged reservoirs
+        total = ctx.irradiance()[..., :3] + ctx.image(mqhip.OUT_RESTIR_IRRADIANCE)[..., :3]
+        assert np.isfinite(total).all() and total.sum() > 0
+    finally:
+        ctx.enable_counters(False)
+        ctx.set_property("debug: freeze learning", 0)
+    o.close()
