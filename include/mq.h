@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MQ_ABI_VERSION 2
+#define MQ_ABI_VERSION 3
 
 enum {
     MQ_OK = 0,
@@ -120,7 +120,8 @@ typedef struct mq_counters {
     uint64_t rays, nodes, tris, segments, guided_segments, lc_touches, mc_updates_accepted,
         mc_updates_dropped, mc_state_reads, pixels;
     uint64_t queue_rays, queue_nodes, queue_tris; /* the bounce-ray traversal kernel alone */
-    uint64_t queue_overflow;                       /* != 0 since connect (never expected): bit 0 a ray queue, bit 1 the update queue ran out of room */
+    uint64_t queue_overflow;                       /* != 0 since connect (never expected): bit 0 a ray queue, bit 1 the update queue ran out of room, bit 2 the packet walk's stack;
+                                                    * bit 3: on a rank of a row partition a reprojected pixel lay beyond the rows the rank holds (raise "band: reprojection halo") */
 } mq_counters;
 
 typedef struct mq_ctx mq_ctx;
@@ -255,7 +256,7 @@ int mq_debug_section_clocks(mq_ctx* ctx, uint64_t* out, int n, int reset);
  * Call after mq_process of the same frame, on the same stream.  Properties: "accum: alpha", "accum: max history",
  * "accum: normal threshold", "accum: depth threshold", "accum: enable motion vectors", "accum: reuse border" and the
  * same six with the prefix "volume accum: " (mq_load_properties_json(ctx, json, "accum") reads them from a graph file).
- * Needs the whole image on this context (mq_set_partition(0, 1)). */
+ * On a rank of a partitioned frame (mq_set_partition, world > 1) the chain covers the rank's row band, see "row partition" below. */
 int mq_post_process(mq_ctx* ctx, void* stream);
 /* the nodes' "clear event": the next mq_post_process starts a new history */
 int mq_post_clear(mq_ctx* ctx);
@@ -269,7 +270,7 @@ int mq_post_clear(mq_ctx* ctx);
  * (radians), "restir: temporal depth threshold", "restir: temporal clamp m", "restir: temporal bias correction",
  * "restir: boiling filter strength", "restir: apply mv", "restir: spatial reuse iterations", "restir: spatial normal
  * threshold", "restir: spatial depth threshold", "restir: spatital radius" (sic), "restir: spatial bias correction",
- * "restir: shade visibility".  Needs the whole image on this context (partition 0 of 1). */
+ * "restir: shade visibility".  On a rank of a partitioned frame the node covers the rank's row band, see "row partition" below. */
 int mq_restir_process(mq_ctx* ctx, const mq_uniform* u, int render, void* stream);
 
 /* ---- multi-GPU framebuffer sharding (no reference counterpart) ----
@@ -285,6 +286,34 @@ int mq_untile(mq_ctx* ctx, const void* gathered_dev, void* stream);
 int mq_untile_to(mq_ctx* ctx, const void* gathered_dev, void* image_dev, void* stream);
 /* the same for the gathered MQ_OUT_VOLUME_TILES buffers -> MQ_OUT_VOLUME */
 int mq_untile_volume(mq_ctx* ctx, const void* gathered_dev, void* stream);
+
+/* ---- row partition of the ReSTIR DI node and the post chain (no reference counterpart; BASELINE config 5 on N GPUs) ----
+ * Temporal reuse, spatial reuse and temporal accumulation read OTHER pixels (the reprojected one, neighbours within the spatial
+ * radius: restir_di_temporal_reuse.comp:71-146, restir_di_spatial_reuse.comp:38-66), which the interleaved tiles of the MCPG
+ * node put on other ranks.  These two nodes therefore cut the image into bands of whole tile rows: rank r of mq_set_partition
+ * owns the pixel rows [row_begin, row_end) -- it runs spatial reuse, shading, accumulation and composition there and holds the
+ * result rows of MQ_OUT_RESTIR_* / MQ_OUT_ACCUM* / MQ_OUT_FINAL (images stay full-size and row-indexed on every rank) --,
+ * generates and temporally reuses reservoirs on [reuse_begin, reuse_end) (its rows widened by "restir: spatital radius"), and
+ * needs last frame's reservoirs, accumulated images and g-buffer on [need_begin, need_end) (widened again by the property
+ * "band: reprojection halo", the reach of reprojection in pixel rows; a reprojected pixel beyond it counts as "no history"
+ * and raises bit 3 of mq_counters::queue_overflow).  The g-buffer of those rows the rank renders itself (mq_restir_process does,
+ * or mq_band_gbuffer when only the post chain runs); what it cannot recompute it gets from the rows' owners once per frame:
+ *     for every other rank s:  rows of [need_begin, need_end) that rank s owns:
+ *         copy  rows * row_bytes  from  s's send_base + row * row_bytes  to  this rank's recv_base + row * row_bytes
+ * -- point-to-point (ncclSend/ncclRecv between band neighbours over xGMI; merian-quake_amd/mq_bands.py does it with
+ * torch.distributed.batch_isend_irecv), after mq_restir_process / mq_post_process of frame n and before those of frame n + 1.
+ * Frame order on a rank:  mq_process (interleaved tiles) -> all-gather + mq_untile of the radiance tiles -> mq_restir_process
+ * -> mq_post_process -> halo exchange (-> all-gather of the rows of MQ_OUT_FINAL if one rank wants the whole image). */
+typedef struct mq_band { uint32_t row_begin, row_end, reuse_begin, reuse_end, need_begin, need_end; } mq_band;
+/* the bands of ANY rank of a `world`-way row partition of a width x height image under this context's properties (host arithmetic) */
+int mq_band_layout(const mq_ctx* ctx, uint32_t width, uint32_t height, int rank, int world, mq_band* out);
+/* the g-buffer node's outputs on this rank's rows [need_begin, need_end) for the frame mq_process last started (mq_restir_process
+ * does this itself; call it before mq_post_process when the ReSTIR node is not used) */
+int mq_band_gbuffer(mq_ctx* ctx, const mq_uniform* u, void* stream);
+enum { MQ_HALO_RESTIR_RESERVOIRS = 0, /* 64 B/pixel: MQ_OUT_RESTIR_RESERVOIRS -> the node's delay-1 input "reservoirs" */
+       MQ_HALO_ACCUM = 1, MQ_HALO_ACCUM_HISTORY = 2, MQ_HALO_VOLUME_ACCUM = 3, MQ_HALO_VOLUME_ACCUM_HISTORY = 4, /* 16 / 4 B/pixel: the accumulate nodes' prev_out / prev_history */
+       MQ_HALO_COUNT = 5 };
+int mq_map_halo(mq_ctx* ctx, int which, void** send_base, void** recv_base, size_t* row_bytes);
 
 /* ---- closest-hit ray queries against the committed scene (raytrace.glsl:82-119 semantics) ---- */
 int mq_trace_rays(mq_ctx* ctx, const float* org_host, const float* dir_host, uint32_t n,

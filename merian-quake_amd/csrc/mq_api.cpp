@@ -47,8 +47,8 @@ int mq_launch_restir_wavefront(const MqSceneDev& sc, const MqParams& P, const Mq
 int mq_launch_restir(const MqSceneDev& sc, const MqParams& P, const MqRestirParams& R, const MqRestirFrame& F, int pass, int grid, hipStream_t s);
 
 // mq_post.hip
-int mq_launch_accumulate(const float* accum_params6, uint32_t W, uint32_t H, const void* src, const void* mv, const void* gb, const void* prev_gb, const void* prev_out, const void* prev_hist, void* out, void* hist, int first, hipStream_t s);
-int mq_launch_compose(uint32_t W, uint32_t H, const void* accum, const void* albedo, const void* vol, const void* emission, void* final_out, hipStream_t s);
+int mq_launch_accumulate(const float* accum_params6, uint32_t W, uint32_t H, const void* src, const void* mv, const void* gb, const void* prev_gb, const void* prev_out, const void* prev_hist, void* out, void* hist, int first, const uint32_t rows[4], uint32_t* flags, hipStream_t s);
+int mq_launch_compose(uint32_t W, uint32_t row_begin, uint32_t row_end, const void* accum, const void* albedo, const void* vol, const void* emission, const void* direct, void* final_out, hipStream_t s);
 int mq_render_block_size();
 int mq_spill_entries();
 
@@ -143,6 +143,9 @@ struct mq_ctx {
     // ev_shaded[p]: the first-hit kernel that read buffer p has finished (the buffer may be overwritten).
     hipStream_t pt_stream = nullptr;
     DevBuf d_prim_hits[2];
+    DevBuf d_band_hits;            // closest hits of the camera rays of a row band's g-buffer (ReSTIR node / post chain of a rank of a partitioned frame)
+    uint32_t slot_tiles = 0;       // tiles the per-slot buffers (path records, hit buffers, ray queues) are sized for: the rank's share of interleaved tiles, or its widest row band
+    bool band_gb_valid = false;    // the g-buffer of this rank's rows has been rendered for the frame mq_process last started
     hipEvent_t ev_pt_done[2] = {}, ev_shaded[2] = {};
     hipEvent_t ev_bounced = nullptr; bool bounced_valid = false; // the last bounce kernel of the previous frame has been issued ("update pass" overlap: the camera rays start behind it)
     bool shaded_valid[2] = {false, false};
@@ -273,7 +276,10 @@ const PropDesc k_props[] = {
     {"restir: spatital radius", PT_INT, POFF(restir_spatial_radius), false, {}},
     {"restir: spatial bias correction", PT_OPTION, POFF(restir_spatial_bias), false, {"none", "basic", "raytraced"}},
     {"restir: shade visibility", PT_BOOL, POFF(restir_shade_visibility), false, {}},
-    {"inline restir rays", PT_BOOL, POFF(restir_inline_rays), false, {}}, // scheduling of this build: trace the generate / shade rays inside the pass kernels instead of through the queues
+    {"inline restir rays", PT_BOOL, POFF(restir_inline_rays), false, {}},
+    // row partition of the ReSTIR node and the post chain over the ranks of mq_set_partition (no reference counterpart), and the `add` node's ReSTIR input
+    {"band: reprojection halo", PT_INT, POFF(band_reprojection_halo), true, {}},
+    {"add: restir irradiance", PT_BOOL, POFF(add_restir), false, {}}, // scheduling of this build: trace the generate / shade rays inside the pass kernels instead of through the queues
     {"debug: freeze learning", PT_BOOL, POFF(freeze_learning), false, {}},
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
     {"debug: LC lock statistics", PT_BOOL, POFF(lc_lock_statistics), false, {}},
@@ -407,7 +413,7 @@ void free_frame_state(mq_ctx* c) {
     dev_free(c->d_restir_pong); dev_free(c->d_restir_prev); dev_free(c->d_restir_prev_gb);
     dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
     dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0; dev_free(c->d_lc_stats); dev_free(c->d_last_upd);
-    dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); c->shaded_valid[0] = c->shaded_valid[1] = false; c->bounced_valid = false;
+    dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); dev_free(c->d_band_hits); c->shaded_valid[0] = c->shaded_valid[1] = false; c->bounced_valid = false;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
@@ -423,6 +429,25 @@ size_t queue_entries_needed(const mq_ctx* c) {
     const size_t local_px = (size_t)c->tiles_per_rank * 64;
     const size_t segs = local_px * ((size_t)std::max(1, c->props.spp) * (size_t)std::max(1, c->props.max_path_length - 1) + (size_t)std::max(0, c->props.volume_spp));
     return segs + segs / 8 + (size_t)MQ_SHARDS * 64 * 4;
+}
+
+// ---- row bands: how the ReSTIR node and the post chain of a partitioned frame are cut ----------
+// Rank r owns the tile rows [tiles_y * r / world, tiles_y * (r + 1) / world): it shades, accumulates and composes those pixels.
+// Spatial reuse reads neighbours up to "restir: spatital radius" pixels away, so the rank generates and temporally reuses
+// reservoirs on its rows widened by ceil(radius / 8) tile rows (`reuse`); temporal reuse and accumulation read last frame's
+// state at a reprojected pixel, which may lie "band: reprojection halo" rows further out still (`need`): the rank renders
+// the g-buffer of those rows itself and receives the other ranks' rows of last frame's reservoirs / accumulated images.
+struct BandRows { uint32_t t0, t1, e0, e1, g0, g1; }; // tile rows: owned, reuse, need
+BandRows band_rows(const MqProps& q, uint32_t H, int rank, int world, int radius_override = -1) {
+    const uint32_t ty = (H + 7) / 8;
+    BandRows b;
+    b.t0 = (uint32_t)((uint64_t)ty * (uint32_t)rank / (uint32_t)world); b.t1 = (uint32_t)((uint64_t)ty * ((uint32_t)rank + 1u) / (uint32_t)world);
+    const int radius = radius_override >= 0 ? radius_override : (q.restir_spatial_iterations > 0 ? std::max(0, q.restir_spatial_radius) : 0);
+    const uint32_t hs = world > 1 ? ((uint32_t)radius + 7u) / 8u : 0u, hm = world > 1 ? ((uint32_t)std::max(0, q.band_reprojection_halo) + 7u) / 8u : 0u;
+    b.e0 = b.t0 > hs ? b.t0 - hs : 0u; b.e1 = std::min(ty, b.t1 + hs);
+    b.g0 = b.e0 > hm ? b.e0 - hm : 0u; b.g1 = std::min(ty, b.e1 + hm);
+    if (b.t0 == b.t1) { b.e0 = b.e1 = b.g0 = b.g1 = b.t0; } // more ranks than tile rows: nothing to do on this one
+    return b;
 }
 
 const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8, 16, 4, 16, 4, 16, 16, 8, 64};
@@ -900,7 +925,13 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     // one region per sub-pipeline + one for the camera rays launched on pt_stream: those run BESIDE the previous frame's
     // kernels (and the ReSTIR / volume passes) on the caller's stream, and a region is indexed by block and thread only
     if ((r = dev_alloc(c, c->d_spill, (size_t)(c->subs + 1) * c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
-    const size_t slots = (size_t)c->tiles_per_rank * 64;
+    // per-slot buffers: the rank's share of interleaved tiles (MCPG node), or -- a rank of a partitioned frame also runs the ReSTIR
+    // node and the g-buffer on a band of rows -- its widest band: rows owned + the largest spatial radius (100) + the reprojection halo
+    c->slot_tiles = c->tiles_per_rank;
+    if (c->world > 1) for (int rk = 0; rk < c->world; rk++) { const BandRows b = band_rows(c->props, h, rk, c->world, 100); c->slot_tiles = std::max(c->slot_tiles, (b.g1 - b.g0) * c->tiles_x); }
+    const size_t slots = (size_t)c->slot_tiles * 64;
+    if (c->world > 1 && (r = dev_alloc(c, c->d_band_hits, slots * 16))) return r;
+    c->band_gb_valid = false;
     if ((r = dev_alloc(c, c->d_paths, slots * 112))) return r; // 7 fields of 16 bytes (the volume pass uses 6)
     if ((r = dev_alloc(c, c->d_debug_rng, (size_t)c->W * c->H * 4))) return r;
     for (int k = 0; k < 2; k++) if ((r = dev_alloc(c, c->d_prim_hits[k], slots * 16))) return r;
@@ -981,7 +1012,8 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     F.slot_begin = sub < 0 ? 0u : c->sub_slot_begin[sub]; F.slot_end = sub < 0 ? c->n_local_tiles * 64u : c->sub_slot_begin[sub + 1];
     F.qctrl = F.ctrl + k * MQ_CTRL_WORDS;
     F.stack_spill = (unsigned long long*)c->d_spill.p + k * c->grid_blocks * mq_render_block_size() * mq_spill_entries();
-    F.paths = (uint4*)c->d_paths.p; F.n_slots = c->tiles_per_rank * 64u;
+    F.paths = (uint4*)c->d_paths.p; F.n_slots = c->slot_tiles * 64u;
+    F.tile_mul = (uint32_t)c->world; F.tile_add = (uint32_t)c->rank;
     F.rays = (float4*)c->d_rays.p + 4 * qoff; F.ray_hits = (uint4*)c->d_ray_hits.p + qoff; // rays: two buffers (round parity) of origins + directions per region
     F.prim_hits = (uint4*)c->d_prim_hits[c->frame_parity & 1].p;
     F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p + qoff; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p + qoff;
@@ -1083,6 +1115,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     }
     const bool first_iteration = c->iteration == 0;
     c->iteration++;
+    c->band_gb_valid = false; // a new frame: the ReSTIR node / post chain of a partitioned frame render the g-buffer of their rows again
     if (!render) { // render_mcpg.cpp:243-250
         int e = mq_launch_clear(F, s);
         if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
@@ -1365,13 +1398,39 @@ int mq_debug_state_write(mq_ctx* c, int which, const void* src, size_t bytes) {
     return MQ_OK;
 }
 
+// The g-buffer node's outputs (hits, gbuffer, mv, albedo, first-hit emission) on the rows a rank of a partitioned frame needs for
+// the ReSTIR node and the post chain (band_rows: owned + spatial radius + reprojection halo).  The MCPG node of that rank renders
+// interleaved tiles; its row band is rendered here, by the same two kernels in their g-buffer-only form (camera rays, first-hit
+// shading: a deterministic function of the pixel, so the values equal what the tiles' own launches wrote).  Once per frame.
+static int ensure_band_gbuffer(mq_ctx* c, const mq_uniform* u, hipStream_t s) {
+    if (c->world == 1 || c->band_gb_valid) return MQ_OK;
+    const BandRows b = band_rows(c->props, c->H, c->rank, c->world);
+    MqFrame F; fill_frame(c, u, F);
+    { int r = frame_grids(c, F); if (r) return r; }
+    F.tile_mul = 1u; F.tile_add = b.g0 * c->tiles_x;
+    F.n_local_tiles = (b.g1 - b.g0) * c->tiles_x;
+    if (F.n_local_tiles > c->slot_tiles) return fail(c, MQ_ESTATE, "row band larger than the buffers of this connect (reconnect after changing the partition)");
+    F.slot_begin = 0u; F.slot_end = F.n_local_tiles * 64u;
+    F.gbuffer_only = 1u;
+    F.prim_hits = (uint4*)c->d_band_hits.p;
+    if (F.n_local_tiles) {
+        int e = mq_launch_primary_trace(c->scene, c->params, F, false, c->grid_frame[3], s);
+        if (!e) e = mq_launch_primary(c->scene, c->params, F, false, false, c->grid_frame[0], s);
+        if (e) return fail(c, MQ_EHIP, std::string("band g-buffer launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    c->band_gb_valid = true;
+    return MQ_OK;
+}
+
 // ---- ReSTIR DI node (mq_restir.h): RendererRESTIR::process, src/render_restir/renderer_restir.cpp:129-251 ----------
+// On a rank of a partitioned frame (mq_set_partition with world > 1) the node works on a band of rows (band_rows above):
+// generate + temporal reuse on the rows it owns widened by the spatial radius, spatial reuse + shade on the rows it owns; the
+// caller then moves the other ranks' rows of the new reservoirs into this rank's "previous reservoirs" (mq_map_halo).
 int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     if (!c || !u) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
     if (!c->connected) return fail(c, MQ_ESTATE, "mq_restir_process before mq_connect");
     if (!c->committed) return fail(c, MQ_ESTATE, "mq_restir_process before mq_scene_commit");
-    if (c->world != 1) return fail(c, MQ_ESTATE, "the ReSTIR node needs the whole image on this context (partition 0 of 1)");
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1381,6 +1440,7 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
         if (q.restir_randomize_seed) { std::random_device dev; std::mt19937 rng(dev()); c->props.restir_seed = (uint32_t)rng(); }
         c->restir_seed_in_use = c->props.restir_seed; c->restir_seeded = true;
     }
+    if (render) { int r = ensure_band_gbuffer(c, u, s); if (r) return r; }
     MqRestirParams R;
     R.spp = q.restir_spp; R.seed = c->restir_seed_in_use; R.visibility_shade = q.restir_shade_visibility;
     R.temporal_normal_reject_cos = (float)std::cos((double)q.restir_temporal_normal_angle); R.temporal_depth_reject = q.restir_temporal_depth;
@@ -1393,6 +1453,13 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
     F.mv = (const uint32_t*)c->d_out[MQ_OUT_GB_MV].p; F.prev_reservoirs = (const uint4*)c->d_restir_prev.p;
     F.irradiance = (float4*)c->d_out[MQ_OUT_RESTIR_IRRADIANCE].p; F.moments = (float2*)c->d_out[MQ_OUT_RESTIR_MOMENTS].p;
     F.stack_spill = (unsigned long long*)c->d_spill.p;
+    F.flags = (uint32_t*)c->d_ctrl.p;
+    // the rows of this rank: `wide` = generate + temporal reuse, `own` = spatial reuse + shade (one rank: both the whole image)
+    const BandRows b = band_rows(q, c->H, c->rank, c->world);
+    const uint32_t wide[2] = {b.e0 * c->tiles_x, b.e1 * c->tiles_x}, own[2] = {b.t0 * c->tiles_x, b.t1 * c->tiles_x};
+    F.slot_tile0 = wide[0]; F.row_lo = b.g0 * 8u; F.row_hi = std::min(c->H, b.g1 * 8u);
+    if (wide[1] - wide[0] > c->slot_tiles && c->world > 1) return fail(c, MQ_ESTATE, "row band larger than the buffers of this connect");
+    auto rows = [&](const uint32_t t[2]) { F.tile_begin = t[0]; F.tile_end = t[1]; };
     uint4* const out = (uint4*)c->d_out[MQ_OUT_RESTIR_RESERVOIRS].p; uint4* const pong = (uint4*)c->d_restir_pong.p;
     if (!c->restir_occ[0]) { // resident blocks per CU of each pass kernel; the spill area holds grid_blocks >= any of these grids
         int e0 = mq_restir_resident_blocks(c->restir_occ);
@@ -1402,10 +1469,10 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
     }
     auto grid_of = [&](int pass) { return std::min(c->grid_blocks, std::max(1, c->cu_count) * c->restir_occ[pass]); };
     const int grid = grid_of(0);
-    const size_t px = (size_t)c->W * c->H;
     int e = 0;
     if (!render) { // renderer_restir.cpp:189-197: the clear pass writes set (1): `reservoirs` = the graph output
         F.res_a = out; F.res_read = pong;
+        rows(own);
         e = mq_launch_restir(c->scene, c->params, R, F, 4, grid, s);
         if (e) return fail(c, MQ_EHIP, std::string("restir clear launch: ") + hipGetErrorString((hipError_t)e));
     } else {
@@ -1428,53 +1495,94 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
             if (!e2) e2 = mq_launch_restir_wavefront(c->scene, c->params, R, F, FQ, which_a + 1, round, grid_of(which_a == 0 ? 0 : 3), s);
             return e2;
         };
+        rows(wide);
         if (wavefront) { for (int smp = 0; smp < std::max(1, R.spp) && !e; smp++) e = traced_pass(0, smp); }
         else e = mq_launch_restir(c->scene, c->params, R, F, 0, grid, s);
         if (!e && q.restir_temporal_reuse && c->restir_iteration > 0) e = mq_launch_restir(c->scene, c->params, R, F, 1, grid_of(1), s);
+        rows(own);
         if (!e && spatial) { F.res_a = out; F.res_read = pong; e = mq_launch_restir(c->scene, c->params, R, F, 2, grid_of(2), s); }
         F.res_a = out; F.res_read = pong;
         if (!e) e = wavefront ? traced_pass(2, std::max(1, R.spp)) : mq_launch_restir(c->scene, c->params, R, F, 3, grid_of(3), s);
         if (e) return fail(c, MQ_EHIP, std::string("restir launch: ") + hipGetErrorString((hipError_t)e));
     }
-    // the graph's delay-1 inputs of the next frame: "reservoirs" and "prev_gbuffer" (renderer_restir.hpp:73-74,86-87)
-    HIPCHK(c, hipMemcpyAsync(c->d_restir_prev.p, out, px * 64, hipMemcpyDeviceToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->d_restir_prev_gb.p, c->d_out[MQ_OUT_GBUFFER].p, px * 16, hipMemcpyDeviceToDevice, s));
+    // the graph's delay-1 inputs of the next frame: "reservoirs" (the rows this rank owns; the others arrive from their owners,
+    // mq_map_halo) and "prev_gbuffer" (every row it holds) (renderer_restir.hpp:73-74,86-87)
+    const size_t r0 = (size_t)b.t0 * 8u * c->W, r1 = (size_t)std::min(c->H, b.t1 * 8u) * c->W; // pixels [r0, r1)
+    const size_t g0 = (size_t)F.row_lo * c->W, g1 = (size_t)F.row_hi * c->W;
+    if (r1 > r0) HIPCHK(c, hipMemcpyAsync((char*)c->d_restir_prev.p + r0 * 64, (const char*)out + r0 * 64, (r1 - r0) * 64, hipMemcpyDeviceToDevice, s));
+    if (g1 > g0) HIPCHK(c, hipMemcpyAsync((char*)c->d_restir_prev_gb.p + g0 * 16, (const char*)c->d_out[MQ_OUT_GBUFFER].p + g0 * 16, (g1 - g0) * 16, hipMemcpyDeviceToDevice, s));
     c->restir_iteration++;
     return MQ_OK;
 }
 
 // ---- post chain (mq_post.hip): accum + volume accum + add ------------------------------------------------------
+// On a rank of a partitioned frame: the rows the rank owns (band_rows), from the gathered `irradiance` / `volume` images (the
+// caller's all-gather + mq_untile / mq_untile_volume come first); last frame's accumulated rows of the other ranks arrive
+// through mq_map_halo.  The volume image then follows the g-buffer's motion vectors: the forward-projected `volume_mv` is a
+// scatter over a rank's own tiles and is not exchanged.
 int mq_post_clear(mq_ctx* c) { if (!c) return MQ_EINVAL; c->post_first = true; return MQ_OK; }
 int mq_post_process(mq_ctx* c, void* stream) {
     if (!c) return MQ_EINVAL;
     if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
     if (!c->connected) return fail(c, MQ_ESTATE, "mq_post_process before mq_connect");
-    if (c->world != 1) return fail(c, MQ_ESTATE, "the post chain needs the whole image on this context (partition 0 of 1)");
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->world > 1 && !c->band_gb_valid) return fail(c, MQ_ESTATE, "mq_post_process on a rank of a partitioned frame needs the g-buffer of its rows: call mq_restir_process or mq_band_gbuffer first");
     const MqProps& q = c->props;
     const float A[2][6] = {{q.accum_alpha, q.accum_max_history, (float)std::cos((double)q.accum_normal_threshold), q.accum_depth_threshold, q.accum_enable_mv ? 1.0f : 0.0f, q.accum_reuse_border ? 1.0f : 0.0f},
                            {q.vaccum_alpha, q.vaccum_max_history, (float)std::cos((double)q.vaccum_normal_threshold), q.vaccum_depth_threshold, q.vaccum_enable_mv ? 1.0f : 0.0f, q.vaccum_reuse_border ? 1.0f : 0.0f}};
-    const int src[2] = {MQ_OUT_IRRADIANCE, MQ_OUT_VOLUME}, mv[2] = {MQ_OUT_GB_MV, MQ_OUT_VOLUME_MV}, out[2] = {MQ_OUT_ACCUM, MQ_OUT_VOLUME_ACCUM}, hist[2] = {MQ_OUT_ACCUM_HISTORY, MQ_OUT_VOLUME_ACCUM_HISTORY};
-    const size_t px = (size_t)c->W * c->H;
+    const int src[2] = {MQ_OUT_IRRADIANCE, MQ_OUT_VOLUME}, mv[2] = {MQ_OUT_GB_MV, c->world > 1 ? MQ_OUT_GB_MV : MQ_OUT_VOLUME_MV}, out[2] = {MQ_OUT_ACCUM, MQ_OUT_VOLUME_ACCUM}, hist[2] = {MQ_OUT_ACCUM_HISTORY, MQ_OUT_VOLUME_ACCUM_HISTORY};
+    const BandRows b = band_rows(q, c->H, c->rank, c->world);
+    const uint32_t rows[4] = {b.t0 * 8u, std::min(c->H, b.t1 * 8u), b.g0 * 8u, std::min(c->H, b.g1 * 8u)};
     for (int k = 0; k < 2; k++) {
         // volume accum.mv <- render_markovchain.volume_mv: only written by frames with a volume pass; without one there is no motion to follow
         const bool have_vmv = k == 0 || (c->params.volume_spp > 0 && !c->volume_outputs_zero);
         float Ak[6]; memcpy(Ak, A[k], sizeof Ak); if (!have_vmv) Ak[4] = 0.0f;
         int e = mq_launch_accumulate(Ak, c->W, c->H, c->d_out[src[k]].p, c->d_out[mv[k]].p, c->d_out[MQ_OUT_GBUFFER].p, c->d_post_prev_gb.p, c->d_post_prev_out[k].p, c->d_post_prev_hist[k].p,
-                                     c->d_out[out[k]].p, c->d_out[hist[k]].p, c->post_first ? 1 : 0, s);
+                                     c->d_out[out[k]].p, c->d_out[hist[k]].p, c->post_first ? 1 : 0, rows, (uint32_t*)c->d_ctrl.p, s);
         if (e) return fail(c, MQ_EHIP, std::string("accumulate launch: ") + hipGetErrorString((hipError_t)e));
     }
-    int e = mq_launch_compose(c->W, c->H, c->d_out[MQ_OUT_ACCUM].p, c->d_out[MQ_OUT_GB_ALBEDO].p, c->d_out[MQ_OUT_VOLUME_ACCUM].p, c->d_out[MQ_OUT_GB_IRRADIANCE].p, c->d_out[MQ_OUT_FINAL].p, s);
+    int e = mq_launch_compose(c->W, rows[0], rows[1], c->d_out[MQ_OUT_ACCUM].p, c->d_out[MQ_OUT_GB_ALBEDO].p, c->d_out[MQ_OUT_VOLUME_ACCUM].p, c->d_out[MQ_OUT_GB_IRRADIANCE].p,
+                              q.add_restir ? c->d_out[MQ_OUT_RESTIR_IRRADIANCE].p : nullptr, c->d_out[MQ_OUT_FINAL].p, s);
     if (e) return fail(c, MQ_EHIP, std::string("compose launch: ") + hipGetErrorString((hipError_t)e));
-    // the graph's delay-1 connections (prev_out, prev_history, prev_gbuffer)
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(c, hipMemcpyAsync(c->d_post_prev_out[k].p, c->d_out[out[k]].p, px * 16, hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->d_post_prev_hist[k].p, c->d_out[hist[k]].p, px * 4, hipMemcpyDeviceToDevice, s));
+    // the graph's delay-1 connections (prev_out, prev_history: the rows this rank owns; prev_gbuffer: every row it holds)
+    const size_t r0 = (size_t)rows[0] * c->W, r1 = (size_t)rows[1] * c->W, g0 = (size_t)rows[2] * c->W, g1 = (size_t)rows[3] * c->W;
+    for (int k = 0; k < 2 && r1 > r0; k++) {
+        HIPCHK(c, hipMemcpyAsync((char*)c->d_post_prev_out[k].p + r0 * 16, (const char*)c->d_out[out[k]].p + r0 * 16, (r1 - r0) * 16, hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync((char*)c->d_post_prev_hist[k].p + r0 * 4, (const char*)c->d_out[hist[k]].p + r0 * 4, (r1 - r0) * 4, hipMemcpyDeviceToDevice, s));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_post_prev_gb.p, c->d_out[MQ_OUT_GBUFFER].p, px * 16, hipMemcpyDeviceToDevice, s));
+    if (g1 > g0) HIPCHK(c, hipMemcpyAsync((char*)c->d_post_prev_gb.p + g0 * 16, (const char*)c->d_out[MQ_OUT_GBUFFER].p + g0 * 16, (g1 - g0) * 16, hipMemcpyDeviceToDevice, s));
     c->post_first = false;
     c->last_stream = s;
+    return MQ_OK;
+}
+
+// ---- row partition of the ReSTIR node / post chain: layout query, the band's g-buffer alone, the halo buffers ----------
+int mq_band_layout(const mq_ctx* c, uint32_t width, uint32_t height, int rank, int world, mq_band* out) {
+    if (!c || !out || !width || !height || world < 1 || rank < 0 || rank >= world) return MQ_EINVAL;
+    const BandRows b = band_rows(c->props, height, rank, world);
+    out->row_begin = std::min(height, b.t0 * 8u); out->row_end = std::min(height, b.t1 * 8u);
+    out->reuse_begin = std::min(height, b.e0 * 8u); out->reuse_end = std::min(height, b.e1 * 8u);
+    out->need_begin = std::min(height, b.g0 * 8u); out->need_end = std::min(height, b.g1 * 8u);
+    return MQ_OK;
+}
+int mq_band_gbuffer(mq_ctx* c, const mq_uniform* u, void* stream) {
+    if (!c || !u) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context: no HIP device");
+    if (!c->connected || !c->committed) return fail(c, MQ_ESTATE, "mq_band_gbuffer before mq_connect / mq_scene_commit");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->params_dirty) props_to_params(c);
+    c->last_stream = (hipStream_t)stream;
+    return ensure_band_gbuffer(c, u, (hipStream_t)stream);
+}
+int mq_map_halo(mq_ctx* c, int which, void** send_base, void** recv_base, size_t* row_bytes) {
+    if (!c || which < 0 || which >= MQ_HALO_COUNT) return MQ_EINVAL;
+    if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
+    static const int outs[MQ_HALO_COUNT] = {MQ_OUT_RESTIR_RESERVOIRS, MQ_OUT_ACCUM, MQ_OUT_ACCUM_HISTORY, MQ_OUT_VOLUME_ACCUM, MQ_OUT_VOLUME_ACCUM_HISTORY};
+    DevBuf* const prev[MQ_HALO_COUNT] = {&c->d_restir_prev, &c->d_post_prev_out[0], &c->d_post_prev_hist[0], &c->d_post_prev_out[1], &c->d_post_prev_hist[1]};
+    if (send_base) *send_base = c->d_out[outs[which]].p;
+    if (recv_base) *recv_base = prev[which]->p;
+    if (row_bytes) *row_bytes = (size_t)c->W * k_bpp[outs[which]];
     return MQ_OK;
 }
 

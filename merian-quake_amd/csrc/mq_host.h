@@ -94,6 +94,8 @@ struct MqProps {
     int restir_temporal_clamp_m = 32 * 20, restir_temporal_bias = 0; float restir_boiling = 0.0f; bool restir_apply_mv = false;
     int restir_spatial_iterations = 0; float restir_spatial_normal_angle = 0.28379410920832787f, restir_spatial_depth = 0.1f;
     int restir_spatial_radius = 30, restir_spatial_bias = 0; bool restir_shade_visibility = false;
+    int band_reprojection_halo = 64; // rows of last frame's state a rank of a row partition holds beyond what the spatial radius needs (the reach of temporal reprojection)
+    bool add_restir = false;         // the `add` node's input for the ReSTIR node: final += restir irradiance * albedo (config 5: "ReSTIR DI + MCPG GI combined")
     bool restir_inline_rays = false; // scheduling of this build: generate / shade rays traced inside the pass kernels (the first implementation) instead of as a wavefront through the MCPG node's queues
     // named quirk switches: on = what the reference's shaders compute, off = the evident intent
     bool quirk_lc_max_wo_p = true; // mcpg.comp:170 `max(wo_p, 10)`

@@ -42,6 +42,8 @@ struct Hit { // res/shader/hit.glsl.h:6-17
     float roughness;
 };
 
+// image tile of local tile `ltile` of this launch (interleaved partition, or a band of tile rows: MqFrame::tile_mul)
+#define MQ_GTILE(F, ltile) ((ltile) * (F).tile_mul + (F).tile_add)
 // position of entry k of shard `shard` in a sharded queue (see "sharded queues" below)
 MQ_DEV uint32_t shard_pos(uint32_t shard, uint32_t k) { return (((k >> 6) * MQ_SHARDS + shard) << 6) | (k & 63u); }
 
@@ -1141,7 +1143,7 @@ __global__ __launch_bounds__(MQ_BLOCK, 7) void mq_primary_trace_kernel(MqSceneDe
     const uint32_t child = (uint32_t)lane & 7u; // the child slot this lane tests
     for (uint32_t tile = first_tile + blockIdx.x * MQ_WAVES + (uint32_t)wave; tile < end_tile; tile += n_waves) {
         const uint32_t my = (tile << 6) | (uint32_t)lane;
-        const uint32_t gtile = tile * F.world + F.rank;
+        const uint32_t gtile = MQ_GTILE(F, tile);
         const uint32_t tx = gtile % F.tiles_x, ty = gtile / F.tiles_x;
         const uint32_t px = tx * 8u + ((uint32_t)lane & 7u), py = ty * 8u + ((uint32_t)lane >> 3);
         const bool valid = px < F.W && py < F.H;
@@ -1214,7 +1216,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_primary_trace_lanes
     const float Wf = (float)F.W, Hf = (float)F.H;
     Ctr ctr = {};
     for (uint32_t my = F.slot_begin + blockIdx.x * MQ_BLOCK + threadIdx.x; my < total; my += gridDim.x * MQ_BLOCK) {
-        const uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+        const uint32_t gtile = MQ_GTILE(F, my >> 6), within = my & 63u;
         const uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
         if (px >= F.W || py >= F.H) continue;
         const f3 up = F3(U.cam_u[0], U.cam_u[1], U.cam_u[2]), fw = F3(U.cam_w[0], U.cam_w[1], U.cam_w[2]);
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
     const float Wf = (float)F.W, Hf = (float)F.H;
     const f3 gb_sun = P.gbuffer_hide_sun ? F3(0.0f, 0.0f, 0.0f) : F3(P.sun_color[0], P.sun_color[1], P.sun_color[2]);
     Ctr ctr = {};
-    if (blockIdx.x == 0 && threadIdx.x < MQ_SHARDS && F.slot_begin == 0u) F.active_ctrl[threadIdx.x * MQ_SHARD_STRIDE] = 0u; // the link pass of this frame lists from 0 (the last frame's apply pass is done)
+    if (blockIdx.x == 0 && threadIdx.x < MQ_SHARDS && F.slot_begin == 0u && !F.gbuffer_only) F.active_ctrl[threadIdx.x * MQ_SHARD_STRIDE] = 0u; // the link pass of this frame lists from 0 (the last frame's apply pass is done)
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (total - F.slot_begin + stride - 1) / stride;
     PSTART(ctr);
@@ -1252,7 +1254,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
         PLAP(ctr, 0);
         if (my < total) {
             uint32_t ltile = my >> 6, within = my & 63u;
-            uint32_t gtile = ltile * F.world + F.rank;
+            uint32_t gtile = MQ_GTILE(F, ltile);
             uint32_t tx = gtile % F.tiles_x, ty = gtile / F.tiles_x;
             p.px = tx * 8u + (within & 7u); p.py = ty * 8u + (within >> 3);
             if (p.px < F.W && p.py < F.H) {
@@ -1296,7 +1298,8 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
                 }
                 PLAP(ctr, 3);
                 // mcpg.comp:44: pixels whose first hit carries no albedo get zero irradiance
-                if ((h.albedo.x >= 1e-7f || h.albedo.y >= 1e-7f || h.albedo.z >= 1e-7f) && P.spp > 0 && P.max_path_length > 1) {
+                if (F.gbuffer_only) {} // a row band's g-buffer for the ReSTIR node / the post chain of a rank: the MCPG outputs are not this launch's
+                else if ((h.albedo.x >= 1e-7f || h.albedo.y >= 1e-7f || h.albedo.z >= 1e-7f) && P.spp > 0 && P.max_path_length > 1) {
                     load_chit(rec, p.cur); // the surface pass starts from the COMPRESSED first hit (mcpg.comp:46-47)
                     p.thr = F3(1, 1, 1); p.fval = F3(0, 0, 0); p.pp = 1.0f; p.seg = 1; p.smp = 0; p.irr = F3(0, 0, 0); p.m2 = 0.0f;
                     cont = advance_path<GUIDED, COUNT>(P, F, p, my, true, false, lobes, ctr);
@@ -1696,7 +1699,7 @@ __global__ void mq_forward_project_kernel(MqParams P, MqFrame F) { // volume_for
     const float Wf = (float)F.W, Hf = (float)F.H;
     const uint32_t total = F.n_local_tiles * 64u;
     for (uint32_t my = blockIdx.x * blockDim.x + threadIdx.x; my < total; my += gridDim.x * blockDim.x) {
-        uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+        uint32_t gtile = MQ_GTILE(F, my >> 6), within = my & 63u;
         uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
         if (px >= F.W || py >= F.H) continue;
         float prev_depth = h2f(F.prev_volume_depth[(size_t)py * F.W + px]);
@@ -1733,7 +1736,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_volume_sample_kerne
         VPath v = {};
         f3 first_wi = F3(0, 0, 1);
         if (my < total) {
-            uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+            uint32_t gtile = MQ_GTILE(F, my >> 6), within = my & 63u;
             uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
             if (px < F.W && py < F.H) {
                 const size_t pidx = (size_t)py * F.W + px;
@@ -1917,7 +1920,7 @@ __global__ void mq_volume_finish_kernel(MqParams P, MqFrame F) { // volume.comp:
     const uint32_t total = F.n_local_tiles * 64u;
     const float inv = 1.0f / (float)(P.volume_spp > 1 ? P.volume_spp : 1);
     for (uint32_t my = blockIdx.x * blockDim.x + threadIdx.x; my < total; my += gridDim.x * blockDim.x) {
-        uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+        uint32_t gtile = MQ_GTILE(F, my >> 6), within = my & 63u;
         uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
         if (px >= F.W || py >= F.H) continue;
         uint4 a = F.paths[my];
@@ -2076,7 +2079,7 @@ __global__ void mq_debug_view_kernel(MqParams P, MqFrame F) {
     const mq_uniform& U = F.u;
     const uint32_t total = F.n_local_tiles * 64u;
     for (uint32_t my = blockIdx.x * blockDim.x + threadIdx.x; my < total; my += gridDim.x * blockDim.x) {
-        uint32_t gtile = (my >> 6) * F.world + F.rank, within = my & 63u;
+        uint32_t gtile = MQ_GTILE(F, my >> 6), within = my & 63u;
         uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
         if (px >= F.W || py >= F.H) continue;
         const size_t pidx = (size_t)py * F.W + px;

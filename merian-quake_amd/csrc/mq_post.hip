@@ -30,9 +30,12 @@ struct MqAccumParams {
 
 __global__ __launch_bounds__(256) void mq_accumulate_kernel(MqAccumParams A, uint32_t W, uint32_t H, const float4* __restrict__ src, const uint32_t* __restrict__ mv,
                                                             const uint4* __restrict__ gb, const uint4* __restrict__ prev_gb, const float4* __restrict__ prev_out,
-                                                            const float* __restrict__ prev_hist, float4* __restrict__ out, float* __restrict__ hist, int first) {
-    const size_t n = (size_t)W * H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+                                                            const float* __restrict__ prev_hist, float4* __restrict__ out, float* __restrict__ hist, int first,
+                                                            uint32_t row_begin, uint32_t row_end, uint32_t row_lo, uint32_t row_hi, uint32_t* flags) {
+    // rows [row_begin, row_end): what this rank accumulates (the whole image on one rank); [row_lo, row_hi): the rows whose
+    // previous-frame state it holds -- a reprojected pixel beyond them is flagged (overflow bit 3) and starts a new history
+    const size_t n = (size_t)W * row_end;
+    for (size_t i = (size_t)W * row_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t ix = (uint32_t)(i % W), iy = (uint32_t)(i / W);
         const float4 s = src[i];
         float h = 1.0f;
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(256) void mq_accumulate_kernel(MqAccumParams A, uin
             float qx = floorf(((float)ix + mx) + 0.5f), qy = floorf(((float)iy + my) + 0.5f);
             bool valid = qx >= 0.0f && qy >= 0.0f && qx < (float)W && qy < (float)H; // NaN motion vectors fail here
             if (!valid && A.reuse_border && qx == qx && qy == qy) { qx = mclamp(qx, 0.0f, (float)W - 1.0f); qy = mclamp(qy, 0.0f, (float)H - 1.0f); valid = true; }
+            if (valid && !((uint32_t)qy >= row_lo && (uint32_t)qy < row_hi)) { atomicOr(flags, 8u); valid = false; }
             if (valid) {
                 const size_t q = (size_t)(uint32_t)qy * W + (uint32_t)qx;
                 const uint4 g = gb[i], pg = prev_gb[q];
@@ -60,29 +64,31 @@ __global__ __launch_bounds__(256) void mq_accumulate_kernel(MqAccumParams A, uin
     }
 }
 
-// final = accum * albedo + volume accum + first-hit emission (alpha = 1)
-__global__ __launch_bounds__(256) void mq_compose_kernel(uint32_t W, uint32_t H, const float4* __restrict__ accum, const uint2* __restrict__ albedo, const float4* __restrict__ vol,
-                                                         const uint2* __restrict__ emission, float4* __restrict__ final_out) {
-    const size_t n = (size_t)W * H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+// final = accum * albedo + volume accum + first-hit emission (alpha = 1); with `direct` (property "add: restir irradiance",
+// BASELINE config 5 "ReSTIR DI + MCPG GI combined": one more input of the graph's `add` node): + direct * albedo
+__global__ __launch_bounds__(256) void mq_compose_kernel(uint32_t W, uint32_t row_begin, uint32_t row_end, const float4* __restrict__ accum, const uint2* __restrict__ albedo, const float4* __restrict__ vol,
+                                                         const uint2* __restrict__ emission, const float4* __restrict__ direct, float4* __restrict__ final_out) {
+    const size_t n = (size_t)W * row_end;
+    for (size_t i = (size_t)W * row_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float4 a = accum[i], v = vol[i];
         const uint2 al = albedo[i], em = emission[i];
-        final_out[i] = make_float4((a.x * h2f((uint16_t)(al.x & 0xffffu)) + v.x) + h2f((uint16_t)(em.x & 0xffffu)),
-                                   (a.y * h2f((uint16_t)(al.x >> 16)) + v.y) + h2f((uint16_t)(em.x >> 16)),
-                                   (a.z * h2f((uint16_t)(al.y & 0xffffu)) + v.z) + h2f((uint16_t)(em.y & 0xffffu)), 1.0f);
+        const float ar = h2f((uint16_t)(al.x & 0xffffu)), ag = h2f((uint16_t)(al.x >> 16)), ab = h2f((uint16_t)(al.y & 0xffffu));
+        float4 o = make_float4((a.x * ar + v.x) + h2f((uint16_t)(em.x & 0xffffu)), (a.y * ag + v.y) + h2f((uint16_t)(em.x >> 16)), (a.z * ab + v.z) + h2f((uint16_t)(em.y & 0xffffu)), 1.0f);
+        if (direct) { const float4 d = direct[i]; o.x = o.x + d.x * ar; o.y = o.y + d.y * ag; o.z = o.z + d.z * ab; }
+        final_out[i] = o;
     }
 }
 
 int mq_launch_accumulate(const float* accum_params6, uint32_t W, uint32_t H, const void* src, const void* mv, const void* gb, const void* prev_gb, const void* prev_out, const void* prev_hist,
-                         void* out, void* hist, int first, hipStream_t s) {
+                         void* out, void* hist, int first, const uint32_t rows[4], uint32_t* flags, hipStream_t s) {
     MqAccumParams A;
     A.alpha = accum_params6[0]; A.max_history = accum_params6[1]; A.cos_normal_threshold = accum_params6[2]; A.depth_threshold = accum_params6[3];
     A.enable_mv = accum_params6[4] != 0.0f; A.reuse_border = accum_params6[5] != 0.0f;
     mq_accumulate_kernel<<<2048, 256, 0, s>>>(A, W, H, (const float4*)src, (const uint32_t*)mv, (const uint4*)gb, (const uint4*)prev_gb, (const float4*)prev_out, (const float*)prev_hist,
-                                              (float4*)out, (float*)hist, first);
+                                              (float4*)out, (float*)hist, first, rows[0], rows[1], rows[2], rows[3], flags);
     return (int)hipGetLastError();
 }
-int mq_launch_compose(uint32_t W, uint32_t H, const void* accum, const void* albedo, const void* vol, const void* emission, void* final_out, hipStream_t s) {
-    mq_compose_kernel<<<2048, 256, 0, s>>>(W, H, (const float4*)accum, (const uint2*)albedo, (const float4*)vol, (const uint2*)emission, (float4*)final_out);
+int mq_launch_compose(uint32_t W, uint32_t row_begin, uint32_t row_end, const void* accum, const void* albedo, const void* vol, const void* emission, const void* direct, void* final_out, hipStream_t s) {
+    mq_compose_kernel<<<2048, 256, 0, s>>>(W, row_begin, row_end, (const float4*)accum, (const uint2*)albedo, (const float4*)vol, (const uint2*)emission, (const float4*)direct, (float4*)final_out);
     return (int)hipGetLastError();
 }

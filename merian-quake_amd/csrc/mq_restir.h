@@ -110,7 +110,7 @@ MQ_DEV RestirPixel restir_pixel(const MqRestirFrame& F, uint32_t tile, int lane)
 // restir_di_generate_samples_bsdf.comp:23-62
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F) {
     MQ_RESTIR_SETUP
-    for (uint32_t tile = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.n_tiles; tile += n_waves) {
+    for (uint32_t tile = F.tile_begin + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.tile_end; tile += n_waves) {
         const RestirPixel p = restir_pixel(F, tile, lane);
         if (!p.inside) continue;
         uint32_t rng = pcg4d16(p.px, p.py, U.frame * 4u + 0u, R.seed);
@@ -161,12 +161,12 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_a_k
     const mq_uniform& U = F.u;
     uint32_t* scratch = (uint32_t*)FQ.paths;
     const uint32_t n_waves = gridDim.x * MQ_WAVES;
-    const uint32_t tiles_per_wave = (F.n_tiles + n_waves - 1) / n_waves;
+    const uint32_t tiles_per_wave = (F.tile_end - F.tile_begin + n_waves - 1) / n_waves;
     for (uint32_t it = 0; it < tiles_per_wave; it++) { // every lane of a wave runs the same trips: the append is wave-wide
-        const uint32_t tile = it * n_waves + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
+        const uint32_t tile = F.tile_begin + it * n_waves + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
         bool push = false; f3 ro = F3(0, 0, 0), wo = F3(0, 0, 1);
-        const uint32_t slot = tile * 64u + (uint32_t)lane;
-        if (tile < F.n_tiles) {
+        const uint32_t slot = (tile - F.slot_tile0) * 64u + (uint32_t)lane; // pixel slots count from the first tile of the rank's rows
+        if (tile < F.tile_end) {
             const RestirPixel p = restir_pixel(F, tile, lane);
             if (p.inside) {
                 Hit first; load_chit(F.hits + 10 * p.idx, first);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_b_k
         const bool valid = queue_valid(qv, q < n ? q : 0u);
         if (!(q < n && valid)) continue;
         const uint32_t slot = FQ.queue_slots[smp & 1][q];
-        const RestirPixel p = restir_pixel(F, slot >> 6, (int)(slot & 63u));
+        const RestirPixel p = restir_pixel(F, (slot >> 6) + F.slot_tile0, (int)(slot & 63u));
         Hit first; load_chit(F.hits + 10 * p.idx, first);
         const float4 d4 = ray_buffer(FQ, smp)[(size_t)FQ.ray_cap + q];
         const f3 wo = F3(d4.x, d4.y, d4.z);
@@ -229,12 +229,12 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_generate_b_k
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_a_kernel(MqRestirParams R, MqRestirFrame F, MqFrame FQ, int round) {
     const int lane = threadIdx.x & 63;
     const uint32_t n_waves = gridDim.x * MQ_WAVES;
-    const uint32_t tiles_per_wave = (F.n_tiles + n_waves - 1) / n_waves;
+    const uint32_t tiles_per_wave = (F.tile_end - F.tile_begin + n_waves - 1) / n_waves;
     for (uint32_t it = 0; it < tiles_per_wave; it++) {
-        const uint32_t tile = it * n_waves + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
+        const uint32_t tile = F.tile_begin + it * n_waves + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6);
         bool push = false; f3 ro = F3(0, 0, 0), wo = F3(0, 0, 1);
-        const uint32_t slot = tile * 64u + (uint32_t)lane;
-        if (tile < F.n_tiles) {
+        const uint32_t slot = (tile - F.slot_tile0) * 64u + (uint32_t)lane; // pixel slots count from the first tile of the rank's rows
+        if (tile < F.tile_end) {
             const RestirPixel p = restir_pixel(F, tile, lane);
             if (p.inside) {
                 const Reservoir r = res_load(F.res_a + 4 * p.idx);
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_b_kern
         const bool valid = queue_valid(qv, q < n ? q : 0u);
         if (!(q < n && valid)) continue;
         const uint32_t slot = FQ.queue_slots[round & 1][q];
-        const RestirPixel p = restir_pixel(F, slot >> 6, (int)(slot & 63u));
+        const RestirPixel p = restir_pixel(F, (slot >> 6) + F.slot_tile0, (int)(slot & 63u));
         Reservoir r = res_load(F.res_a + 4 * p.idx);
         Hit first; load_chit(F.hits + 10 * p.idx, first);
         const f3 dv = r.pos - first.pos;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_b_kern
 // restir_di_temporal_reuse.comp:71-146 (+ the boiling filter, :37-69, over the 8x8 tile = this wave)
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_temporal_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F) {
     MQ_RESTIR_SETUP
-    for (uint32_t tile = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.n_tiles; tile += n_waves) {
+    for (uint32_t tile = F.tile_begin + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.tile_end; tile += n_waves) {
         const RestirPixel p = restir_pixel(F, tile, lane);
         bool active = p.inside;
         Reservoir r = res_init();
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_temporal_ker
             const uint32_t m = F.mv[p.idx];
             const float qx = floorf(((float)p.px + h2f((uint16_t)(m & 0xffffu))) + 0.5f), qy = floorf(((float)p.py + h2f((uint16_t)(m >> 16))) + 0.5f);
             active = qx >= 0.0f && qy >= 0.0f && qx < (float)F.W && qy < (float)F.H; // :82-84 (a NaN motion vector leaves the image too)
+            if (active && !((uint32_t)qy >= F.row_lo && (uint32_t)qy < F.row_hi)) { atomicOr(F.flags, 8u); active = false; } // a rank of a row partition: beyond the rows it holds (flagged: "restir: reprojection halo" is too small for this motion)
             if (active) {
                 const size_t q = (size_t)(uint32_t)qy * F.W + (uint32_t)qx;
                 const uint4 g = F.gbuffer[p.idx], pg = F.prev_gbuffer[q];
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_temporal_ker
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_spatial_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F) {
     MQ_RESTIR_SETUP
     const int NI = R.spatial_reuse_iterations < 1 ? 1 : (R.spatial_reuse_iterations > MQ_RESTIR_MAX_NEIGHBORS ? MQ_RESTIR_MAX_NEIGHBORS : R.spatial_reuse_iterations);
-    for (uint32_t tile = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.n_tiles; tile += n_waves) {
+    for (uint32_t tile = F.tile_begin + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.tile_end; tile += n_waves) {
         const RestirPixel p = restir_pixel(F, tile, lane);
         if (!p.inside) continue;
         uint32_t rng = pcg4d16(p.px, p.py, U.frame * 4u + 2u, R.seed);
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_spatial_kern
             const float nx = floorf(((float)p.px + (float)R.spatial_radius * (2.0f * x0 - 1.0f)) + 0.5f), ny = floorf(((float)p.py + (float)R.spatial_radius * (2.0f * x1 - 1.0f)) + 0.5f);
             nq[i] = MQ_NIL;
             if (!(nx >= 0.0f && ny >= 0.0f && nx < (float)F.W && ny < (float)F.H)) continue;
+            if (!((uint32_t)ny >= F.row_lo && (uint32_t)ny < F.row_hi)) { atomicOr(F.flags, 8u); continue; } // (cannot happen: the rows a rank holds include the spatial radius)
             const uint32_t q = (uint32_t)ny * F.W + (uint32_t)nx;
             const uint4 ng = F.gbuffer[q];
             if (!reprojection_valid(decode_normal(g.x), decode_normal(ng.x), R.spatial_normal_reject_cos, __uint_as_float(g.y), __uint_as_float(g.w), __uint_as_float(ng.y), R.spatial_depth_reject)) continue;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_spatial_kern
 // restir_di_shade.comp:21-62
 __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_restir_shade_kernel(MqSceneDev sc, MqParams P, MqRestirParams R, MqRestirFrame F) {
     MQ_RESTIR_SETUP
-    for (uint32_t tile = blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.n_tiles; tile += n_waves) {
+    for (uint32_t tile = F.tile_begin + blockIdx.x * MQ_WAVES + (threadIdx.x >> 6); tile < F.tile_end; tile += n_waves) {
         const RestirPixel p = restir_pixel(F, tile, lane);
         if (!p.inside) continue;
         Reservoir r = res_load(F.res_a + 4 * p.idx);

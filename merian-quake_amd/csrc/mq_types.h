@@ -200,6 +200,10 @@ struct MqFrame {
     uint32_t n_local_tiles; // tiles this rank renders
     uint32_t slot_begin, slot_end; // the pixel slots (64 per local tile) of the sub-pipeline this launch belongs to; [0, n_local_tiles * 64) = the whole rank
     uint32_t rank, world;
+    // pixel slot -> tile of the image: local tile l is global tile l * tile_mul + tile_add.  (world, rank): the interleaved
+    // partition of the MCPG node; (1, first tile of a band of tile rows): the g-buffer of a row band (ReSTIR / post chain on a rank)
+    uint32_t tile_mul, tile_add;
+    uint32_t gbuffer_only; // the first-hit kernel writes the g-buffer node's outputs only (no estimator, no radiance, no rays)
     // outputs
     float* irradiance;     // W*H*4 (full image, linear index) -- written for local tiles only
     float* tiles_out;      // n_local_tiles*64*4
@@ -271,6 +275,12 @@ struct MqRestirParams { // the specialisation constants of renderer_restir.cpp:1
 struct MqRestirFrame {
     mq_uniform u;
     uint32_t W, H, tiles_x, n_tiles;
+    // Row bands (mq_set_partition with world > 1): a launch covers the global tiles [tile_begin, tile_end) -- whole tile rows --;
+    // pixel slots (scratch, queue entries) are numbered from slot_tile0; rows [row_lo, row_hi) are those whose g-buffer and
+    // previous-frame state this rank holds: a reprojected pixel outside them raises overflow bit 3 (flags[0] |= 8) and
+    // counts as "no history".  One rank: [0, n_tiles), 0, [0, H).
+    uint32_t tile_begin, tile_end, slot_tile0, row_lo, row_hi;
+    uint32_t* flags;
     const uint32_t* hits;      // gbuffer "hits" (CompressedHit, 10 dwords per pixel)
     const uint4* gbuffer;      // gbuffer "gbuffer"
     const uint4* prev_gbuffer; // the same, one frame ago

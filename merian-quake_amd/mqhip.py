@@ -22,6 +22,7 @@ MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
  OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_DEBUG, OUT_ACCUM, OUT_ACCUM_HISTORY, OUT_VOLUME_ACCUM, OUT_VOLUME_ACCUM_HISTORY, OUT_FINAL,
  OUT_RESTIR_IRRADIANCE, OUT_RESTIR_MOMENTS, OUT_RESTIR_RESERVOIRS, OUT_COUNT) = range(21)
 MQ_ENODEVICE = -2
+HALO_RESTIR_RESERVOIRS, HALO_ACCUM, HALO_ACCUM_HISTORY, HALO_VOLUME_ACCUM, HALO_VOLUME_ACCUM_HISTORY, HALO_COUNT = range(6)
 
 EXT_DTYPE = np.dtype([("texnum_alpha", "<u2"), ("texnum_fb_flags", "<u2"), ("n0_gloss_norm", "<u4"),
                       ("n1_brush", "<u4"), ("n2", "<u4"), ("st", "<u2", (6,))])
@@ -40,6 +41,11 @@ class Uniform(C.Structure):
 
 
 assert C.sizeof(Uniform) == 124
+
+
+class Band(C.Structure):
+    """mq_band: the pixel rows of one rank of a row partition (owned / + spatial radius / + reprojection halo)"""
+    _fields_ = [(n, C.c_uint32) for n in ("row_begin", "row_end", "reuse_begin", "reuse_end", "need_begin", "need_end")]
 
 
 class Constants(C.Structure):
@@ -170,6 +176,9 @@ def load_library(path=None):
         "mq_untile": (i32, [P, vp, vp]),
         "mq_untile_volume": (i32, [P, vp, vp]),
         "mq_untile_to": (i32, [P, vp, vp, vp]),
+        "mq_band_layout": (i32, [P, u32, u32, i32, i32, C.POINTER(Band)]),
+        "mq_band_gbuffer": (i32, [P, C.POINTER(Uniform), vp]),
+        "mq_map_halo": (i32, [P, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]),
         "mq_trace_rays": (i32, [P, vp, vp, u32, vp, vp, vp]),
         "mq_math_eval": (i32, [P, i32, vp, vp, u32]),
         "mq_synth_scene": (i32, [P, C.c_char_p, u32]),
@@ -490,6 +499,21 @@ class Context:
         t, b = C.c_uint32(), C.c_size_t()
         self._chk(self.lib.mq_tiles_per_rank(self.h, C.byref(t), C.byref(b)))
         return t.value, b.value
+
+    # -- row partition of the ReSTIR node / post chain
+    def band_layout(self, w, h, rank, world):
+        b = Band()
+        self._chk(self.lib.mq_band_layout(self.h, w, h, rank, world, C.byref(b)))
+        return b
+
+    def band_gbuffer(self, uniform, stream=None):
+        self._chk(self.lib.mq_band_gbuffer(self.h, C.byref(uniform), stream))
+
+    def map_halo(self, which):
+        """(send base pointer, receive base pointer, bytes per pixel row) of halo buffer `which` (HALO_*)"""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.mq_map_halo(self.h, which, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     def untile(self, gathered_dev_ptr, stream=None):
         self._chk(self.lib.mq_untile(self.h, gathered_dev_ptr, stream))

@@ -111,7 +111,7 @@ struct orc_ctx {
     /* post chain */
     float post_par[2][6];
     float* post_out[2]; float* post_hist[2]; float* post_prev_out[2]; float* post_prev_hist[2]; gbuf_t* post_prev_gb; float* post_final;
-    int post_first; int volume_ran;
+    int post_first; int volume_ran; int post_add_restir; /* the `add` node's input for the ReSTIR node's irradiance (times albedo) */
     struct orc_pool* pool; /* persistent worker threads of the multi-threaded passes */
     int parallel_update;   /* orc_process_mt flag: the update pass over the workers too (racy, like the reference's dispatch) */
 };
@@ -1791,6 +1791,7 @@ const void* orc_restir_output(orc_ctx* c, int which, size_t* bytes) {
 
 /* ---------------------------------------------------------------- post chain (definitions: DESIGN.md section 3) */
 
+int orc_post_set_add_restir(orc_ctx* c, int on) { c->post_add_restir = on != 0; return 0; }
 int orc_post_set_params(orc_ctx* c, int which, const float* six) { if (which < 0 || which > 1) return -1; memcpy(c->post_par[which], six, 24); return 0; }
 void orc_post_clear(orc_ctx* c) { c->post_first = 1; }
 const void* orc_post_output(orc_ctx* c, int which, size_t* bytes) {
@@ -1839,7 +1840,11 @@ int orc_post_process(orc_ctx* c) {
     accumulate(c, 1, c->volume, c->volume_ran ? c->volume_mv : NULL); /* volume_mv exists only after a volume pass */
     for (size_t i = 0; i < px; i++) { /* add: accum * albedo (the denoiser node's re-modulation) + volume accum + first-hit emission */
         const float* a = c->post_out[0] + 4 * i; const float* v = c->post_out[1] + 4 * i; float* f = c->post_final + 4 * i;
-        for (int ch = 0; ch < 3; ch++) f[ch] = (a[ch] * orc_h2f(c->gb_albedo[4 * i + ch]) + v[ch]) + orc_h2f(c->gb_irr[4 * i + ch]);
+        for (int ch = 0; ch < 3; ch++) {
+            const float al = orc_h2f(c->gb_albedo[4 * i + ch]);
+            f[ch] = (a[ch] * al + v[ch]) + orc_h2f(c->gb_irr[4 * i + ch]);
+            if (c->post_add_restir && c->rs_irr) f[ch] = f[ch] + c->rs_irr[4 * i + ch] * al; /* config 5: + ReSTIR DI irradiance, re-modulated like the MCPG irradiance */
+        }
         f[3] = 1.0f;
     }
     for (int k = 0; k < 2; k++) { memcpy(c->post_prev_out[k], c->post_out[k], px * 16); memcpy(c->post_prev_hist[k], c->post_hist[k], px * 4); }

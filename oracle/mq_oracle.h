@@ -181,6 +181,7 @@ int orc_debug_apply_updates(orc_ctx* c, const uint32_t* records, size_t n, const
  * RGBA32F, 3 volume accum history R32F, 4 final RGBA32F. */
 int orc_post_set_params(orc_ctx* c, int which, const float* six);
 int orc_post_process(orc_ctx* c); /* after orc_process of the same frame */
+int orc_post_set_add_restir(orc_ctx* c, int on); /* final += ReSTIR irradiance * albedo (the product's "add: restir irradiance") */
 void orc_post_clear(orc_ctx* c);
 const void* orc_post_output(orc_ctx* c, int which, size_t* bytes);
 

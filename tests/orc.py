@@ -103,6 +103,7 @@ def lib():
         l.orc_restir_output.argtypes = [P, C.c_int, C.POINTER(C.c_size_t)]
         l.orc_post_set_params.argtypes = [P, C.c_int, P]
         l.orc_post_process.argtypes = [P]
+        l.orc_post_set_add_restir.argtypes = [P, C.c_int]
         l.orc_post_clear.argtypes = [P]
         l.orc_post_output.restype = C.c_void_p
         l.orc_post_output.argtypes = [P, C.c_int, C.POINTER(C.c_size_t)]
@@ -221,6 +222,7 @@ class Oracle:
         for k, prefix in enumerate(("accum: ", "volume accum: ")):
             six = np.array([ctx.get_property(prefix + n) for n in ("alpha", "max history", "normal threshold", "depth threshold", "enable motion vectors", "reuse border")], np.float32)
             assert self.l.orc_post_set_params(self.h, k, _ptr(six)) == 0
+        self.l.orc_post_set_add_restir(self.h, int(ctx.get_property("add: restir irradiance")))
 
     def post_process(self):
         assert self.l.orc_post_process(self.h) == 0

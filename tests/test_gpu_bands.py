@@ -1,0 +1,152 @@
+"""BASELINE config 5 on N ranks: the ReSTIR DI node and the post chain on a ROW partition (include/mq.h "row partition",
+DESIGN.md section 7), emulated with K contexts on one GPU.  Temporal reuse reads last frame's reservoir at the reprojected
+pixel and spatial reuse reads neighbours within the spatial radius (restir_di_temporal_reuse.comp:71-146,
+restir_di_spatial_reuse.comp:38-66; pass order renderer_restir.cpp:206-250); accumulation reads last frame's accumulated
+pixel at the reprojected position.  Every rank renders its interleaved MCPG tiles, the tile buffers are gathered (what
+the RCCL all-gather does), each rank then runs both nodes on its band, and the halo rows move between the contexts exactly
+as merian-quake_amd/mq_bands.py plans them for torch.distributed.  Bar: every rank's rows of the reservoirs (all 64 bytes),
+the ReSTIR irradiance / moments, the accumulated image + history and the FINAL image are bit-identical to the one-rank nodes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
+
+PROPS = {"reference mode": 1, "randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3, "adaptive grid buf size": 1 << 16, "static grid buf size": 1 << 12,
+         "LC buf size": 1 << 14, "restir: randomize seed": 0, "restir: seed": 77, "restir: spp": 2, "restir: enable temporal reuse": 1,
+         "restir: temporal bias correction": "basic", "restir: boiling filter strength": 0.3, "restir: spatial reuse iterations": 2, "restir: spatital radius": 12,
+         "restir: spatial bias correction": "raytraced", "restir: shade visibility": 1, "add: restir irradiance": 1, "band: reprojection halo": 24, "accum: alpha": 0.9}
+
+
+def _make(scene, seed, props, W, H, rank, world):
+    import mqhip
+    c = mqhip.Context(0)
+    c.header_defaults()
+    c.synth_scene(scene, seed)
+    for k, v in props.items():
+        c.set_property(k, v)
+    c.commit(); c.set_partition(rank, world); c.connect(W, H)
+    return c
+
+
+def _frame_on_ranks(ranks, u, torch, mqhip):
+    """One frame on K emulated ranks: MCPG tiles -> gather + untile on every rank -> ReSTIR node -> post chain."""
+    for c in ranks:
+        c.process(u)
+    gathered = torch.cat([torch.from_numpy(c.read_output(mqhip.OUT_TILES).view(np.float32).copy()) for c in ranks]).cuda()
+    for c in ranks:
+        c.untile(gathered.data_ptr())
+    torch.cuda.synchronize()
+    for c in ranks:
+        c.restir_process(u)
+        c.post_process()
+    torch.cuda.synchronize()
+
+
+OUTS = ("OUT_RESTIR_RESERVOIRS", "OUT_RESTIR_IRRADIANCE", "OUT_RESTIR_MOMENTS", "OUT_ACCUM", "OUT_ACCUM_HISTORY", "OUT_FINAL", "OUT_GBUFFER", "OUT_HITS")
+
+
+@pytest.mark.parametrize("world,W,H,scene", [(2, 200, 120, "synth_start"), (3, 150, 90, "synth_materials"), (4, 328, 200, "synth_start"), (8, 328, 200, "synth_start")])
+def test_restir_and_post_chain_on_row_bands_equal_the_single_rank_nodes(mqlib, world, W, H, scene):
+    import torch
+    import mqhip
+    import mq_bands
+    single = _make(scene, 4, PROPS, W, H, 0, 1)
+    ranks = [_make(scene, 4, PROPS, W, H, r, world) for r in range(world)]
+    bands = mq_bands.bands_of(single, W, H, world)
+    assert bands[0].row_begin == 0 and bands[-1].row_end == H and all(bands[r].row_end == bands[r + 1].row_begin for r in range(world - 1))
+    which = [mqhip.HALO_RESTIR_RESERVOIRS, mqhip.HALO_ACCUM, mqhip.HALO_ACCUM_HISTORY, mqhip.HALO_VOLUME_ACCUM, mqhip.HALO_VOLUME_ACCUM_HISTORY]
+    pairs = [mq_bands.halo_tensors(c, H, which) for c in ranks]
+    merged = 0
+    for f in range(6):
+        u = single.synth_camera(40 + 2 * f)  # a moving camera: reprojection crosses band borders
+        single.process(u); single.restir_process(u); single.post_process()
+        _frame_on_ranks(ranks, u, torch, mqhip)
+        for name in OUTS:
+            want = single.read_output(getattr(mqhip, name)).view(np.uint8).reshape(H, -1)
+            for r, c in enumerate(ranks):
+                b = bands[r]
+                got = c.read_output(getattr(mqhip, name)).view(np.uint8).reshape(H, -1)
+                bad = (got[b.row_begin:b.row_end] != want[b.row_begin:b.row_end]).any(1)
+                assert not bad.any(), "frame %d, %s, rank %d of %d: %d of its %d rows differ, first row %d" % (f, name, r, world, bad.sum(), b.row_end - b.row_begin, b.row_begin + int(np.argmax(bad)))
+        mq_bands.exchange_local(pairs, bands)  # halo rows of the new state -> the neighbours' "previous frame" buffers
+        torch.cuda.synchronize()
+        res = single.read_output(mqhip.OUT_RESTIR_RESERVOIRS).view(np.uint32).reshape(-1, 16)
+        merged = max(merged, int(res[:, 0].max()))
+    assert merged > 2 * PROPS["restir: spp"], merged  # temporal + spatial reuse really merged reservoirs
+    fin = single.image(mqhip.OUT_FINAL)
+    assert np.isfinite(fin).all() and fin[..., :3].sum() > 0
+    assert single.read_output(mqhip.OUT_ACCUM_HISTORY).view(np.float32).max() >= 4  # histories survived the moving camera somewhere
+    for c in ranks + [single]:
+        assert c.counters()["queue_overflow"] == 0
+        c.close()
+
+
+def test_too_small_a_reprojection_halo_is_flagged(mqlib):
+    """A reprojected pixel beyond the rows a rank holds counts as "no history" and raises bit 3 of queue_overflow -- never a
+    read of rows the rank does not have, never silent.  Forced with a halo of 0 rows and a camera that jumps."""
+    import torch
+    import mqhip
+    import mq_bands
+    W, H, world = 200, 120, 4
+    props = {**PROPS, "band: reprojection halo": 0, "restir: spatial reuse iterations": 0}
+    ranks = [_make("synth_start", 4, props, W, H, r, world) for r in range(world)]
+    bands = mq_bands.bands_of(ranks[0], W, H, world)
+    pairs = [mq_bands.halo_tensors(c, H, [mqhip.HALO_RESTIR_RESERVOIRS, mqhip.HALO_ACCUM, mqhip.HALO_ACCUM_HISTORY]) for c in ranks]
+    assert all(b.need_begin == b.row_begin and b.need_end == b.row_end for b in bands)
+    for f in (40, 48, 56):
+        _frame_on_ranks(ranks, ranks[0].synth_camera(f), torch, mqhip)
+        mq_bands.exchange_local(pairs, bands)
+    flags = [c.counters()["queue_overflow"] for c in ranks]
+    assert any(fl & 8 for fl in flags) and not any(fl & 7 for fl in flags), flags
+    for c in ranks:
+        assert np.isfinite(c.image(mqhip.OUT_FINAL)).all()
+        c.close()
+
+
+def test_config5_azad_4k_on_eight_bands(mqlib):
+    """Config 5's frame, 3840x2160 on synth_azad, the ReSTIR node + post chain as rank 3 and rank 7 of 8 row bands against the
+    one-rank nodes (MCPG unguided here: its radiance comes in through the gather in every case, see
+    tests/test_restir.py::test_config5_azad_4k_restir_plus_guided_mcpg for the guided estimator at this size)."""
+    import torch
+    import mqhip
+    import mq_bands
+    W, H, world = 3840, 2160, 8
+    props = {**PROPS, "restir: spp": 1, "restir: spatial reuse iterations": 1, "restir: spatital radius": 30, "restir: spatial bias correction": "none",
+             "band: reprojection halo": 128}  # this fly-through moves pixels by up to 118 rows per frame at 4K (gb mv): a halo below that is flagged (bit 3), not wrong
+    single = _make("synth_azad", 4, props, W, H, 0, 1)
+    bands = mq_bands.bands_of(single, W, H, world)
+    picks = (3, 7)
+    ranks = {r: _make("synth_azad", 4, props, W, H, r, world) for r in picks}
+    which = [mqhip.HALO_RESTIR_RESERVOIRS, mqhip.HALO_ACCUM, mqhip.HALO_ACCUM_HISTORY]
+    spairs = mq_bands.halo_tensors(single, H, which)
+    pairs = {r: mq_bands.halo_tensors(c, H, which) for r, c in ranks.items()}
+    for f in (40, 41, 42):
+        u = single.synth_camera(f)
+        single.process(u); single.restir_process(u); single.post_process()
+        full = torch.as_tensor(mq_bands._DevRows(single.map_output(mqhip.OUT_IRRADIANCE)[0], H, W * 16), device="cuda")
+        for r, c in ranks.items():
+            c.process(u)  # (its own interleaved tiles; the gathered image is the single context's -- bit-identical in reference mode, tests/test_gpu_multi.py)
+            torch.as_tensor(mq_bands._DevRows(c.map_output(mqhip.OUT_IRRADIANCE)[0], H, W * 16), device="cuda").copy_(full)
+            c.restir_process(u); c.post_process()
+        torch.cuda.synchronize()
+        for name in ("OUT_RESTIR_RESERVOIRS", "OUT_RESTIR_IRRADIANCE", "OUT_ACCUM", "OUT_FINAL"):
+            want = single.read_output(getattr(mqhip, name)).view(np.uint8).reshape(H, -1)
+            for r, c in ranks.items():
+                b = bands[r]
+                got = c.read_output(getattr(mqhip, name)).view(np.uint8).reshape(H, -1)
+                assert np.array_equal(got[b.row_begin:b.row_end], want[b.row_begin:b.row_end]), (f, name, r)
+        # the halo rows come from the single context, which holds every other rank's rows of the new state
+        for r in picks:
+            _, recvs = mq_bands.plan(bands, r)
+            for k in range(len(which)):
+                for _, r0, r1 in recvs:
+                    pairs[r][k][1][r0:r1].copy_(spairs[k][0][r0:r1])
+        torch.cuda.synchronize()
+    for c in list(ranks.values()) + [single]:
+        assert c.counters()["queue_overflow"] == 0
+        c.close()

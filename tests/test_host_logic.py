@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(mq, mqlib):
     for name in declared:
         assert hasattr(mqlib, name), "libmqhip.so does not export %s" % name
     assert declared == set(mqlib._mq_symbols), declared ^ set(mqlib._mq_symbols)
-    assert mqlib.mq_abi_version() == 2
+    assert mqlib.mq_abi_version() == 3
     assert ctypes.sizeof(mq.Uniform) == 124  # res/shader/scene_info.glsl.h:18-32
     assert mq.EXT_DTYPE.itemsize == 28       # src/game/quake_helpers.hpp:10-34
 
@@ -325,3 +325,21 @@ def test_cpp_node_adapter(built, tmp_path):
                     "-L" + libdir, "-lmqhip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "node adapter ok" in r.stdout, r.stdout
+
+
+def test_deep_chain_scene_needs_more_than_the_lds_stack(mq):
+    """tests/deep_scene.py (used by the GPU suite to exercise the traversal-stack spill area): its central ray keeps 15 entries
+    on the per-lane stack -- the 12 LDS entries are not enough -- as a host replay of the kernel's stack discipline on the
+    BVH the builder really produced shows."""
+    import deep_scene
+    ctx = mq.Context(-1)
+    vtx, idx, ext = deep_scene.chain_scene(80, 1.6)
+    ctx.set_geometry(0, vtx, None, idx, ext, mq.MQ_GEO_OPAQUE | mq.MQ_GEO_STATIC)
+    ctx.commit()
+    nodes, tris = ctx.get_bvh()
+    assert len(tris) == len(idx)
+    depth, visits = deep_scene.emulate_stack_depth(nodes, [0.25, 0, 0], [1, 0, 0])
+    assert depth >= 14 and visits > 40, (depth, visits)
+    depth_back, _ = deep_scene.emulate_stack_depth(nodes, [1.6 ** 80, 0, 0], [-1, 0, 0])
+    assert depth_back <= 2  # looking back from the far end the first box test culls everything beyond T_MAX
+    ctx.close()
