@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1)
     ap.add_argument("--reference-mode", type=int, default=0)
     ap.add_argument("--volume-spp", type=int, default=0)
+    ap.add_argument("--restir", action="store_true", help="BASELINE config 5's frame: the ReSTIR DI node (temporal + spatial reuse) and the post chain (accumulate, compose "
+                    "with the ReSTIR irradiance) behind the MCPG node; on N > 1 ranks they run on row bands with a point-to-point halo exchange per frame")
+    ap.add_argument("--config5", action="store_true", help="--restir on the config-5 workload: synth_azad(seed=4), 3840x2160, 1 spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prop", action="append", default=[], metavar="KEY=VALUE", help="set a renderer property away from the workload's (A/B experiments: the line then names it)")
     ap.add_argument("--bsp", default=None, help="a user-supplied BSP29 / BSP2 map instead of the synthetic stand-in (camera at the player start); "
@@ -156,6 +159,8 @@ def main():
     ap.add_argument("--map", default="ad_sepulcher")
     ap.add_argument("--palette", default=None, help="gfx/palette.lmp for --bsp (default: the loader's built-in grey ramp)")
     args = ap.parse_args()
+    if args.config5:
+        args.restir, args.scene, args.scene_seed, args.width, args.height = True, "synth_azad", 4, 3840, 2160
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -204,6 +209,9 @@ def main():
     ctx.json_defaults()
     props = {"randomize seed": 0, "seed": 0x5EED, "spp": args.spp, "max path length": 3, "reference mode": args.reference_mode,
              "volume spp": args.volume_spp}  # config 3 has no volumes; config 4 (synth_tears, fog) renders them
+    if args.restir:  # config 5: "ReSTIR DI + MCPG GI combined" -- both nodes on one g-buffer, their radiance summed by the `add` node
+        props.update({"restir: randomize seed": 0, "restir: seed": 77, "restir: spp": 1, "restir: enable temporal reuse": 1, "restir: spatial reuse iterations": 1,
+                      "add: restir irradiance": 1, "band: reprojection halo": max(64, args.height // 16)})  # the fly-through moves pixels by up to H / 18 rows per frame
     extra = {}
     for kv in args.prop:
         k, _, v = kv.partition("=")
@@ -235,7 +243,8 @@ def main():
     # The exchange of frame N overlaps the rendering of frame N + 1: tiles are copied to a staging buffer on the
     # render stream, the RCCL all-gather and the un-tiling into a bench-owned image run on a side stream.
     # MQ_BENCH_SYNC_EXCHANGE=1 keeps everything on the render stream (and un-tiles into MQ_OUT_IRRADIANCE).
-    overlap = exchange and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1" and (not rehearsal or os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") == "2")
+    # (with --restir the nodes behind the MCPG node consume the gathered image of the SAME frame: no overlap with the next one)
+    overlap = exchange and not args.restir and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1" and (not rehearsal or os.environ.get("MQ_BENCH_REHEARSAL_ONE_GPU") == "2")
     if exchange:
         local = torch.as_tensor(_DevArray(tiles_ptr, tile_bytes // 4), device="cuda")
         gathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
@@ -261,14 +270,54 @@ def main():
             dist.all_gather_into_tensor(dst, src)  # the exchange step: RCCL over xGMI
         untile(dst.data_ptr(), stream)
 
+    bands = halo_pairs = plan = final_img = halo_side = halo_group = None
+    halo_recv_bytes = 0
+    if args.restir and exchange:
+        import mq_bands
+        # The halo rows of frame n are first read by the temporal pass of frame n + 1: the exchange (and the row gather of the final
+        # image) runs on a side stream and its own communicator beside the MCPG pass of frame n + 1.  MQ_BENCH_SYNC_EXCHANGE=1: in line.
+        if not rehearsal and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1":
+            halo_side = torch.cuda.Stream()
+            halo_group = dist.new_group(backend="nccl") if world > 1 else None
+        bands = mq_bands.bands_of(ctx, W, H, world)
+        which = [mqhip.HALO_RESTIR_RESERVOIRS, mqhip.HALO_ACCUM, mqhip.HALO_ACCUM_HISTORY] + ([mqhip.HALO_VOLUME_ACCUM, mqhip.HALO_VOLUME_ACCUM_HISTORY] if args.volume_spp > 0 else [])
+        halo_pairs = mq_bands.halo_tensors(ctx, H, which)
+        plan = mq_bands.plan(bands, rank)
+        halo_recv_bytes = mq_bands.halo_bytes(bands, rank, [p[0].shape[1] for p in halo_pairs])
+        final_img = torch.as_tensor(mq_bands._DevRows(ctx.map_output(mqhip.OUT_FINAL)[0], H, W * 16), device="cuda")
+
+    def restir_and_post(u):
+        if halo_side is not None:
+            torch.cuda.current_stream().wait_stream(halo_side)  # last frame's halo rows have landed (they moved beside this frame's MCPG pass)
+        ctx.restir_process(u, True, stream)
+        ctx.post_process(stream)
+        if bands is None:
+            return
+        to_host = (lambda t: t.cpu()) if rehearsal else None  # one shared GPU: stage through gloo
+        if rehearsal:
+            torch.cuda.synchronize()
+        if halo_side is not None:
+            halo_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(halo_side):
+                mq_bands.exchange(dist, halo_pairs, plan[0], plan[1], group=halo_group)
+                mq_bands.gather_rows(dist, final_img, bands, rank, group=halo_group)
+            return
+        mq_bands.exchange(dist, halo_pairs, plan[0], plan[1], stage=to_host)            # neighbours' rows of the new reservoirs / accumulated images
+        mq_bands.gather_rows(dist, final_img, bands, rank, stage=to_host)               # the composed image, whole, on every rank
+
     def step(frame):
-        ctx.process(ctx.synth_camera(frame), True, stream)
+        u = ctx.synth_camera(frame)
+        ctx.process(u, True, stream)
         if not exchange:
+            if args.restir:
+                restir_and_post(u)
             return
         if not overlap:
             gather_sync(gathered, local, ctx.untile)
             if vlocal is not None:
                 gather_sync(vgathered, vlocal, ctx.untile_volume)
+            if args.restir:
+                restir_and_post(u)
             return
         main = torch.cuda.current_stream()
         main.wait_stream(side)          # the previous frame's exchange (it ran beside this frame's kernels) is done
@@ -308,6 +357,9 @@ def main():
         step(frame); frame += 1
     sync_all()
     dt = time.perf_counter() - t0
+    if ctx.counters()["queue_overflow"] != 0:
+        raise SystemExit("bench.py: the run raised overflow flags %d (a queue ran out of room, or -- bit 3 -- a reprojected pixel left the rows a rank holds: "
+                         "raise \"band: reprojection halo\"): the frames are not valid" % ctx.counters()["queue_overflow"])
     if overlap and (rehearsal or selftest):  # rehearsals only: the assembled image must contain this rank's tiles of the last frame
         import mq_tiles
         got = mq_tiles.tile_image(image.cpu().numpy().reshape(H, W, 4), rank, world)
@@ -366,7 +418,7 @@ def main():
     # the update pass ("overlap camera rays"), so the surface-pass interval alone no longer holds all of a frame's work.
     frame_ms = (render_sum + update_sum) / n_timed
     default_workload = (world == 1 and not selftest and (W, H) == (1920, 1080) and args.scene == "synth_sepulcher" and args.scene_seed == 2
-                        and args.spp == 1 and not args.reference_mode and args.volume_spp == 0 and not extra)
+                        and args.spp == 1 and not args.reference_mode and args.volume_spp == 0 and not extra and not args.restir)
     traffic, traffic_src = pmc_traffic(dom, default_workload, learn, args.steps)
     # `achieved` / `frac`: ALGORITHMIC bytes of the dominant kernel per launch over its measured launch time (the contract's
     # definition).  `traffic` is what the HBM actually moved per launch (PMC); `hbm_measured` prices that against the peak:
@@ -393,11 +445,14 @@ def main():
     out = {"metric": "Msamples/s at 1920x1080 1spp (ad_sepulcher); per-pixel L2 vs reference", "value": round(value, 3),
            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "learning_frames": learn, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real" if bsp else "synthetic",
-           "config": {"workload": "%s, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults"
+           "config": {"workload": "%s, %dx%d %dspp, MCPG guiding %s, max path length 3, JSON renderer defaults%s"
                                   % ("user-supplied map %s, camera at the player start" % args.scene if bsp else "%s(seed=%d) stand-in for ad_sepulcher" % (args.scene, args.scene_seed),
-                                     W, H, args.spp, "off (reference mode)" if args.reference_mode else "on"),
+                                     W, H, args.spp, "off (reference mode)" if args.reference_mode else "on",
+                                     " + ReSTIR DI node (1 candidate, temporal + spatial reuse) + accumulate / compose (config 5)" if args.restir else ""),
                       **({"properties_changed": extra} if extra else {}), "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world, "ranks": world, "backend": (dist.get_backend() if exchange else "none"),
-                      "collective": "none" if not exchange else "%dx RCCL all_gather of %d B/rank per frame%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "")},
+                      "collective": "none" if not exchange else "%dx RCCL all_gather of %d B/rank per frame%s%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "",
+                                    "" if not args.restir else "; row bands for the ReSTIR node / post chain: point-to-point halo rows, %d B received per frame by rank 0, + all_gather of the final image's rows (%d B/rank)"
+                                    % (halo_recv_bytes, max(b.row_end - b.row_begin for b in bands) * W * 16))},
            "roofline": roofline}
     if exchange:
         dist.barrier()  # every rank is done with the GPU: the CPU leg below has the host to itself

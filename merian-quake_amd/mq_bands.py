@@ -4,9 +4,10 @@ Plumbing around the C ABI (include/mq.h, "row partition"): libmqhip decides the 
 (mq_map_halo: full-size, row-indexed images on every rank); this module turns the bands into a list of point-to-point row copies
 and issues them with torch.distributed -- `batch_isend_irecv`, i.e. grouped ncclSend / ncclRecv over RCCL: a band's halo rows
 live on its neighbours, and xGMI gives every pair of GPUs its own link, so each copy runs on a link nobody else uses.
-Per frame and rank at 3840x2160 on 8 ranks (spatial radius 30, reprojection halo 32: 64 rows on either side of a band):
-reservoirs 2 x 64 rows x 3840 px x 64 B = 31.5 MB, accumulated images + histories 2 x 64 x 3840 x 2 x 20 B = 19.7 MB --
-against 531 MB + 332 MB if the images themselves were gathered.
+Per frame and inner rank at 3840x2160 on 8 ranks (spatial radius 30 = 32 rows, reprojection halo 64 rows: 96 rows on either
+side of a band): reservoirs 2 x 96 rows x 3840 px x 64 B = 47.2 MB, accumulated image + history 2 x 96 x 3840 x 20 B = 14.7 MB
+-- against 531 MB + 166 MB if the images themselves were gathered (bench.py --config5 uses a halo of H / 16 = 135 rows: its
+fly-through moves pixels by up to 118 rows per frame; 108 MB).
 """
 import numpy as np
 
@@ -57,21 +58,22 @@ def halo_tensors(ctx, H, which_list):
     return out
 
 
-def exchange(dist, pairs, sends, recvs, stage=None):
+def exchange(dist, pairs, sends, recvs, stage=None, group=None):
     """One halo exchange of this rank: for every (send image, recv image) pair move the planned rows.  `stage`: a function
-    tensor -> tensor applied to what is sent and inverted on what is received (the gloo rehearsal stages through the host)."""
+    tensor -> tensor applied to what is sent and inverted on what is received (the gloo rehearsal stages through the host).
+    `group`: a process group of its own keeps these transfers off the stream of the frame's all-gathers."""
     ops, landed = [], []
     for send_img, recv_img in pairs:
         for peer, r0, r1 in sends:
             t = send_img[r0:r1]
-            ops.append(dist.P2POp(dist.isend, stage(t) if stage else t, peer))
+            ops.append(dist.P2POp(dist.isend, stage(t) if stage else t, peer, group))
         for peer, r0, r1 in recvs:
             t = recv_img[r0:r1]
             if stage:
                 buf = stage(t)
                 landed.append((t, buf))
                 t = buf
-            ops.append(dist.P2POp(dist.irecv, t, peer))
+            ops.append(dist.P2POp(dist.irecv, t, peer, group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
@@ -88,21 +90,27 @@ def exchange_local(pairs_per_rank, bands):
                 recv_img[r0:r1].copy_(pairs_per_rank[peer][k][0][r0:r1])
 
 
-def gather_rows(dist, image, bands, me, stage=None):
+_blocks = {}
+
+
+def gather_rows(dist, image, bands, me, stage=None, group=None):
     """All ranks end up with every rank's owned rows of `image` ([H, row_bytes] tensor, rows a rank owns valid on that rank):
     one all_gather_into_tensor of equal-sized row blocks (the bands differ by at most one tile row: padded to the largest)."""
     import torch
     most = max(b.row_end - b.row_begin for b in bands)
-    blk = torch.zeros((most, image.shape[1]), dtype=image.dtype, device=image.device)
+    key = (most, image.shape[1], str(image.device), len(bands))
+    if key not in _blocks:  # the staging blocks live as long as the process: no allocation, no fill per frame
+        _blocks[key] = (torch.zeros((most, image.shape[1]), dtype=image.dtype, device=image.device), torch.empty((len(bands) * most, image.shape[1]), dtype=image.dtype, device=image.device))
+    blk, allb_dev = _blocks[key]
     mine = bands[me]
     blk[: mine.row_end - mine.row_begin].copy_(image[mine.row_begin:mine.row_end])
     if stage:
         all_cpu = torch.empty((len(bands) * most, image.shape[1]), dtype=image.dtype)
-        dist.all_gather_into_tensor(all_cpu, blk.cpu())
+        dist.all_gather_into_tensor(all_cpu, blk.cpu(), group=group)
         allb = all_cpu.to(image.device)
     else:
-        allb = torch.empty((len(bands) * most, image.shape[1]), dtype=image.dtype, device=image.device)
-        dist.all_gather_into_tensor(allb, blk)
+        allb = allb_dev
+        dist.all_gather_into_tensor(allb, blk, group=group)
     for r, b in enumerate(bands):
         if r != me and b.row_end > b.row_begin:
             image[b.row_begin:b.row_end].copy_(allb[r * most: r * most + (b.row_end - b.row_begin)])

@@ -194,3 +194,28 @@ def test_cpp_node_adapter_renders_on_the_device(mqlib, tmp_path):
         assert np.array_equal(got, want), name
     assert ctx.irradiance()[..., :3].sum() > 0 and ctx.image(mqhip.OUT_FINAL)[..., :3].sum() > 0
     ctx.close()
+
+
+def test_bench_restir_line_on_one_rank(mqlib):
+    """`bench.py --restir`: config 5's frame (MCPG + ReSTIR DI node + accumulate / compose) as the timed step, one rank."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--restir", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                        "--width", "640", "--height", "360", "--scene", "synth_start", "--scene-seed", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and "ReSTIR DI" in line["config"]["workload"] and line["value"] > 0 and line["roofline"]["traffic"] is None
+
+
+def test_bench_restir_two_ranks_rehearsed_on_one_gpu(mqlib):
+    """`bench.py --gpus 2 --restir` end to end with both ranks on this box's one GPU (MQ_BENCH_REHEARSAL_ONE_GPU: gloo-staged
+    exchange, never a measurement): tile all-gather, row bands for the ReSTIR node and the post chain, the point-to-point halo
+    exchange of merian-quake_amd/mq_bands.py, the row gather of the final image -- and no overflow flag (bench.py fails on one)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MQ_BENCH_REHEARSAL_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--restir", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--width", "328", "--height", "200", "--scene", "synth_start", "--scene-seed", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-500:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["backend"] == "gloo" and "halo rows" in line["config"]["collective"] and line["value"] > 0

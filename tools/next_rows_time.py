@@ -1,29 +1,46 @@
 """Wall time per frame of the "next" rows on one GPU (ReSTIR DI node, accumulate + compose) beside the MCPG pass they
-follow: python tools/next_rows_time.py [W H scene seed]   (default: 3840 2160 synth_azad 4 -- BASELINE config 5's frame)"""
+follow, for ONE rank of an N-way partition (no exchange: what `bench.py --gpus N --restir` can reach at best):
+    python tools/next_rows_time.py [W H scene seed] [--worlds 1,2,4,8]     (default: 3840 2160 synth_azad 4 -- BASELINE config 5's frame)
+The MCPG node renders the rank's interleaved tiles; the ReSTIR node and the post chain its row band (+ the g-buffer of the band's
+rows, which the rank renders itself) -- rank N / 2, an inner band with halos on both sides."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
 import mqhip
+import mq_bands
 
-W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
-scene, seed = (sys.argv[3], int(sys.argv[4])) if len(sys.argv) > 4 else ("synth_azad", 4)
-ctx = mqhip.Context(0)
-ctx.json_defaults()
-for k, v in {"randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3, "restir: spp": 1, "restir: enable temporal reuse": 1,
-             "restir: spatial reuse iterations": 1, "restir: randomize seed": 0}.items():
-    ctx.set_property(k, v)
-ctx.synth_scene(scene, seed); ctx.commit(); ctx.connect(W, H)
+argv = sys.argv[1:]
+worlds = [1]
+if "--worlds" in argv:
+    i = argv.index("--worlds"); worlds = [int(x) for x in argv[i + 1].split(",")]; del argv[i:i + 2]
+W, H = (int(argv[0]), int(argv[1])) if len(argv) > 1 else (3840, 2160)
+scene, seed = (argv[2], int(argv[3])) if len(argv) > 3 else ("synth_azad", 4)
+for world in worlds:
+    ctx = mqhip.Context(0)
+    ctx.json_defaults()
+    for k, v in {"randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3, "restir: spp": 1, "restir: enable temporal reuse": 1,
+                 "restir: spatial reuse iterations": 1, "restir: randomize seed": 0, "add: restir irradiance": 1, "band: reprojection halo": max(64, H // 16)}.items():
+        ctx.set_property(k, v)
+    ctx.synth_scene(scene, seed); ctx.commit()
+    rank = world // 2
+    ctx.set_partition(rank, world); ctx.connect(W, H)
+    b = mq_bands.bands_of(ctx, W, H, world)[rank]
 
-def run(frames, what):
-    for f in frames:
-        u = ctx.synth_camera(f)
-        ctx.process(u)
-        if "restir" in what: ctx.restir_process(u)
-        if "post" in what: ctx.post_process()
-    ctx.sync()
+    def run(frames, what):
+        for f in frames:
+            u = ctx.synth_camera(f)
+            ctx.process(u)
+            if "restir" in what: ctx.restir_process(u)
+            elif "post" in what and world > 1: ctx.band_gbuffer(u)
+            if "post" in what: ctx.post_process()
+        ctx.sync()
 
-run(range(0, 40), ("restir", "post"))
-for what in ((), ("restir",), ("post",), ("restir", "post")):
-    t0 = time.perf_counter(); run(range(40, 90), what); dt = (time.perf_counter() - t0) / 50 * 1e3
-    print("%dx%d %s: MCPG%s%s  %.3f ms per frame" % (W, H, scene, " + ReSTIR DI" if "restir" in what else "", " + accumulate/compose" if "post" in what else "", dt), flush=True)
-ctx.close()
+    run(range(0, 40), ("restir", "post"))
+    out = []
+    for what in ((), ("restir",), ("post",), ("restir", "post")):
+        t0 = time.perf_counter(); run(range(40, 90), what); dt = (time.perf_counter() - t0) / 50 * 1e3
+        out.append("MCPG%s%s %.3f ms" % (" + ReSTIR DI" if "restir" in what else "", " + accumulate/compose" if "post" in what else "", dt))
+    halo = mq_bands.halo_bytes(mq_bands.bands_of(ctx, W, H, world), rank, [W * 64, W * 16, W * 4]) if world > 1 else 0
+    print("%dx%d %s, rank %d of %d (rows %d..%d, reuse %d..%d, need %d..%d; %.1f MB of halo rows received per frame): %s; flags %d" % (
+        W, H, scene, rank, world, b.row_begin, b.row_end, b.reuse_begin, b.reuse_end, b.need_begin, b.need_end, halo / 1e6, "; ".join(out), ctx.counters()["queue_overflow"]), flush=True)
+    ctx.close()
