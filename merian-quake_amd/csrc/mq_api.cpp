@@ -68,22 +68,23 @@ struct mq_ctx {
     // committed scene (host copies kept for stats / debugging)
     std::vector<MqNode> nodes;
     std::vector<MqTri> tris;
+    std::vector<MqLeafRec> leaves; // the traversal's leaf records, in the order MqNode::tri_base counts them
     float sah_cost = 0.0f;
     bool committed = false;
     // two trees under one root: static slots (MQ_GEO_STATIC) are rebuilt only when one of them changed, the
     // per-frame slots on every commit (quake_node.cpp:847-983); layout in mq_scene_commit.
-    std::vector<MqNode> s_nodes; std::vector<MqTri> s_tris; // the static tree as built
+    std::vector<MqNode> s_nodes; std::vector<MqTri> s_tris; std::vector<MqLeafRec> s_leaves; // the static tree as built
     float s_sah = 0.0f;
     uint32_t s_depth = 0, d_depth = 0; // levels of 8-wide nodes in the static / per-frame tree (the packet kernel's shared stack must hold them)
     bool static_dirty = true, tex_dirty = true;
     bool joined = false;               // both trees present
-    uint32_t n_static_nodes = 0, n_static_tris = 0; // the static part of nodes / tris
-    uint32_t dev_static_nodes = 0, dev_static_tris = 0; // static part present in the device arrays (joined layout)
+    uint32_t n_static_nodes = 0, n_static_tris = 0, n_static_leaves = 0; // the static part of nodes / tris / leaves
+    uint32_t dev_static_nodes = 0, dev_static_tris = 0, dev_static_leaves = 0; // static part present in the device arrays (joined layout)
     bool dev_scene_valid = false;
     std::vector<MqTexDesc> texdesc;    // of the last full commit: shading records of per-frame triangles need them
     uint32_t commits_full = 0, commits_dynamic = 0;
     // device scene
-    DevBuf d_nodes, d_tris, d_shade, d_texdesc, d_texels;
+    DevBuf d_nodes, d_tris, d_leaves, d_shade, d_texdesc, d_texels;
     DevBuf d_ext[MQ_MAX_GEOMETRIES], d_idx[MQ_MAX_GEOMETRIES], d_prev[MQ_MAX_GEOMETRIES];
     MqSceneDev scene{};
     // frame state
@@ -418,7 +419,7 @@ void free_frame_state(mq_ctx* c) {
     c->connected = false;
 }
 void free_scene_dev(mq_ctx* c) {
-    dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels);
+    dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_leaves); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels);
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
 }
 
@@ -674,10 +675,16 @@ int mq_scene_get_bvh(const mq_ctx* c, const void** nodes, uint64_t* n_nodes, con
     if (nodes) *nodes = c->nodes.data(); if (n_nodes) *n_nodes = c->nodes.size(); if (tris) *tris = c->tris.data(); if (n_tris) *n_tris = c->tris.size();
     return MQ_OK;
 }
+int mq_scene_get_leaves(const mq_ctx* c, const void** leaves, uint64_t* n_leaves) {
+    if (!c) return MQ_EINVAL;
+    if (!c->committed) return MQ_ESTATE;
+    if (leaves) *leaves = c->leaves.data(); if (n_leaves) *n_leaves = c->leaves.size();
+    return MQ_OK;
+}
 int mq_scene_stats(const mq_ctx* c, uint64_t* n_tris, uint64_t* n_nodes, uint64_t* bvh_bytes, float* sah_cost) {
     if (!c) return MQ_EINVAL;
     if (n_tris) *n_tris = c->tris.size(); if (n_nodes) *n_nodes = c->nodes.size();
-    if (bvh_bytes) *bvh_bytes = c->nodes.size() * sizeof(MqNode) + c->tris.size() * sizeof(MqTri);
+    if (bvh_bytes) *bvh_bytes = c->nodes.size() * sizeof(MqNode) + c->leaves.size() * sizeof(MqLeafRec); // what a traversal reads (the 48-byte triangles serve the shading)
     if (sah_cost) *sah_cost = c->sah_cost;
     return MQ_OK;
 }
@@ -741,22 +748,23 @@ int mq_scene_commit(mq_ctx* c) {
     const bool static_rebuilt = c->static_dirty;
     if (c->static_dirty) {
         flatten_slots(c, true, flat);
-        if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, &c->s_sah, err, &c->s_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
+        if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, c->s_leaves, &c->s_sah, err, &c->s_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
         c->static_dirty = false;
     }
-    std::vector<MqNode> d_nodes; std::vector<MqTri> d_tris; float d_sah = 0.0f;
+    std::vector<MqNode> d_nodes; std::vector<MqTri> d_tris; std::vector<MqLeafRec> d_leaves; float d_sah = 0.0f;
     flatten_slots(c, false, flat);
-    if (!mq_build_cwbvh(flat, d_nodes, d_tris, &d_sah, err, &c->d_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
-    const size_t ns = c->s_nodes.size(), nd = d_nodes.size(), ts = c->s_tris.size(), td = d_tris.size();
+    if (!mq_build_cwbvh(flat, d_nodes, d_tris, d_leaves, &d_sah, err, &c->d_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
+    const size_t ns = c->s_nodes.size(), nd = d_nodes.size(), ts = c->s_tris.size(), td = d_tris.size(), ls = c->s_leaves.size(), ld = d_leaves.size();
     // layout: the static tree as built, then the per-frame tree (indices offset); the traversal starts at node 0 and
     // visits the per-frame root (MqSceneDev::dyn_root) last.  Without static geometry the per-frame tree is the tree.
     const bool joined = ns != 0 && nd != 0;
-    const bool in_place = !static_rebuilt && c->nodes.size() >= ns && c->tris.size() >= ts; // the static part is where it was
-    if (!in_place) { c->nodes = c->s_nodes; c->tris = c->s_tris; }
-    c->nodes.resize(ns + nd); c->tris.resize(ts + td);
-    for (size_t j = 0; j < nd; j++) { MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ts; c->nodes[ns + j] = n; }
+    const bool in_place = !static_rebuilt && c->nodes.size() >= ns && c->tris.size() >= ts && c->leaves.size() >= ls; // the static part is where it was
+    if (!in_place) { c->nodes = c->s_nodes; c->tris = c->s_tris; c->leaves = c->s_leaves; }
+    c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + ld);
+    for (size_t j = 0; j < nd; j++) { MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ls; c->nodes[ns + j] = n; }
     std::copy(d_tris.begin(), d_tris.end(), c->tris.begin() + (ptrdiff_t)ts);
-    c->n_static_nodes = (uint32_t)ns; c->n_static_tris = (uint32_t)ts;
+    for (size_t j = 0; j < ld; j++) { MqLeafRec r = d_leaves[j]; r.tri0 += (uint32_t)ts; c->leaves[ls + j] = r; }
+    c->n_static_nodes = (uint32_t)ns; c->n_static_tris = (uint32_t)ts; c->n_static_leaves = (uint32_t)ls;
     c->joined = joined;
     c->sah_cost = c->s_sah + d_sah;
     c->committed = true;
@@ -764,13 +772,15 @@ int mq_scene_commit(mq_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     int r;
-    const bool partial = in_place && !c->tex_dirty && c->dev_scene_valid && c->dev_static_nodes == ns && c->dev_static_tris == ts
-        && c->d_nodes.bytes >= c->nodes.size() * sizeof(MqNode) && c->d_tris.bytes >= c->tris.size() * sizeof(MqTri) && c->d_shade.bytes >= c->tris.size() * sizeof(MqShadeRec);
+    const bool partial = in_place && !c->tex_dirty && c->dev_scene_valid && c->dev_static_nodes == ns && c->dev_static_tris == ts && c->dev_static_leaves == ls
+        && c->d_nodes.bytes >= c->nodes.size() * sizeof(MqNode) && c->d_tris.bytes >= c->tris.size() * sizeof(MqTri) && c->d_shade.bytes >= c->tris.size() * sizeof(MqShadeRec)
+        && c->d_leaves.bytes >= c->leaves.size() * sizeof(MqLeafRec);
     if (partial) { // per-frame geometry only: root pair, the per-frame tree, its triangles and shading records
         std::vector<MqShadeRec> recs;
         shade_records(c, c->tris.data() + ts, td, recs);
         if (nd) HIPCHK(c, hipMemcpy((MqNode*)c->d_nodes.p + ns, c->nodes.data() + ns, nd * sizeof(MqNode), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy((MqTri*)c->d_tris.p + ts, c->tris.data() + ts, td * sizeof(MqTri), hipMemcpyHostToDevice));
+        if (ld) HIPCHK(c, hipMemcpy((MqLeafRec*)c->d_leaves.p + ls, c->leaves.data() + ls, ld * sizeof(MqLeafRec), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy((MqShadeRec*)c->d_shade.p + ts, recs.data(), td * sizeof(MqShadeRec), hipMemcpyHostToDevice));
         if ((r = upload_slot_arrays(c, false))) return r;
         c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
@@ -785,6 +795,8 @@ int mq_scene_commit(mq_ctx* c) {
     const size_t slack_tris = td + 16384, slack_nodes = nd + 8192;
     if ((r = dev_alloc(c, c->d_nodes, (c->nodes.size() + slack_nodes) * sizeof(MqNode)))) return r;
     if ((r = dev_alloc(c, c->d_tris, (c->tris.size() + slack_tris) * sizeof(MqTri)))) return r;
+    if ((r = dev_alloc(c, c->d_leaves, (c->leaves.size() + slack_tris) * sizeof(MqLeafRec)))) return r; // (at most one record per triangle)
+    if (!c->leaves.empty()) HIPCHK(c, hipMemcpy(c->d_leaves.p, c->leaves.data(), c->leaves.size() * sizeof(MqLeafRec), hipMemcpyHostToDevice));
     if ((r = dev_alloc(c, c->d_shade, (c->tris.size() + slack_tris) * sizeof(MqShadeRec)))) return r;
     if (!c->nodes.empty()) HIPCHK(c, hipMemcpy(c->d_nodes.p, c->nodes.data(), c->nodes.size() * sizeof(MqNode), hipMemcpyHostToDevice));
     if (!c->tris.empty()) HIPCHK(c, hipMemcpy(c->d_tris.p, c->tris.data(), c->tris.size() * sizeof(MqTri), hipMemcpyHostToDevice));
@@ -842,12 +854,12 @@ int mq_scene_commit(mq_ctx* c) {
         if (!recs.empty()) HIPCHK(c, hipMemcpy(c->d_shade.p, recs.data(), recs.size() * sizeof(MqShadeRec), hipMemcpyHostToDevice));
     }
     if ((r = dev_upload(c, c->d_texels, lin.data(), lin.size() * 4))) return r;
-    c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p; c->scene.shade = (const MqShadeRec*)c->d_shade.p;
+    c->scene.nodes = (const MqNode*)c->d_nodes.p; c->scene.tris = (const MqTri*)c->d_tris.p; c->scene.leaves = (const MqLeafRec*)c->d_leaves.p; c->scene.shade = (const MqShadeRec*)c->d_shade.p;
     c->scene.tex = (const MqTexDesc*)c->d_texdesc.p; c->scene.texels = (const float4*)c->d_texels.p;
     c->scene.n_nodes = (uint32_t)c->nodes.size(); c->scene.n_tris = (uint32_t)c->tris.size();
     c->scene.dyn_root = joined ? (uint32_t)ns : MQ_NIL;
     c->tex_dirty = false; c->dev_scene_valid = true;
-    c->dev_static_nodes = (uint32_t)ns; c->dev_static_tris = (uint32_t)ts;
+    c->dev_static_nodes = (uint32_t)ns; c->dev_static_tris = (uint32_t)ts; c->dev_static_leaves = (uint32_t)ls;
     c->commits_full++;
     return MQ_OK;
 }

@@ -118,9 +118,51 @@ inline float exp2i(int e) { uint32_t b = (uint32_t)(e + 127) << 23; float f; mem
 
 // Build into `out_nodes` / `out_tris` (triangles re-ordered into leaf order). `pad` widens every
 // box so the float slab test stays conservative next to the exact triangle test.
-bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err, uint32_t* depth_out) {
+// Leaf records of one leaf of the binary tree (at most MQ_BVH_LEAF triangles): triangles that share two vertices (bit-equal
+// coordinates) go into one record, the others get a record each.  Appends the triangles to `out_tris` in record order
+// (B right behind A) and returns the number of records.
+static bool same_vtx(const float* a, const float* b) { return memcmp(a, b, 12) == 0; }
+static uint32_t emit_leaf_records(const std::vector<MqTri>& tris, const uint32_t* order, uint32_t count, std::vector<MqTri>& out_tris, std::vector<MqLeafRec>& out_leaves) {
+    bool used[8] = {false, false, false, false, false, false, false, false};
+    uint32_t n_rec = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        if (used[i]) continue;
+        used[i] = true;
+        const MqTri& A = tris[order[i]];
+        const float* av[3] = {A.v0, A.v1, A.v2};
+        MqLeafRec r; memset(&r, 0, sizeof r);
+        for (int k = 0; k < 3; k++) memcpy(r.v[k], av[k], 12);
+        memcpy(r.v[3], A.v0, 12);
+        r.key0 = A.key; r.key1 = MQ_NIL; r.tri0 = (uint32_t)out_tris.size();
+        r.sel = (A.flags & MQ_TRI_ANYHIT) ? 0x10000u : 0u;
+        out_tris.push_back(A);
+        for (uint32_t j = i + 1; j < count; j++) { // a partner: two of its vertices are vertices of A
+            if (used[j]) continue;
+            const MqTri& B = tris[order[j]];
+            const float* bv[3] = {B.v0, B.v1, B.v2};
+            int sel[3], fresh = -1, n_shared = 0;
+            for (int k = 0; k < 3; k++) {
+                sel[k] = -1;
+                for (int m = 0; m < 3; m++) if (same_vtx(bv[k], av[m])) { sel[k] = m; break; }
+                if (sel[k] >= 0) n_shared++; else fresh = k;
+            }
+            if (n_shared < 2) continue;
+            if (fresh >= 0) { sel[fresh] = 3; memcpy(r.v[3], bv[fresh], 12); } // (n_shared == 3: a coincident triangle, no fourth vertex)
+            r.key1 = B.key;
+            r.sel |= (uint32_t)sel[0] | ((uint32_t)sel[1] << 2) | ((uint32_t)sel[2] << 4) | MQ_LEAF_HAS_B | ((B.flags & MQ_TRI_ANYHIT) ? 0x20000u : 0u);
+            out_tris.push_back(B);
+            used[j] = true;
+            break;
+        }
+        out_leaves.push_back(r);
+        n_rec++;
+    }
+    return n_rec;
+}
+
+bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, std::vector<MqLeafRec>& out_leaves, float* sah_cost, std::string& err, uint32_t* depth_out) {
     if (depth_out) *depth_out = 0;
-    out_nodes.clear(); out_tris.clear();
+    out_nodes.clear(); out_tris.clear(); out_leaves.clear();
     if (sah_cost) *sah_cost = 0.0f;
     const uint32_t n = (uint32_t)tris.size();
     if (n == 0) return true;
@@ -212,7 +254,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
         uint32_t n_internal = 0;
         for (int s = 0; s < 8; s++) if (slot_child[s] >= 0 && B.nodes[slot_child[s]].count == 0) n_internal++;
         node.child_base = (uint32_t)out_nodes.size();
-        node.tri_base = (uint32_t)out_tris.size();
+        node.tri_base = (uint32_t)out_leaves.size();
         out_nodes.resize(out_nodes.size() + n_internal);
         uint32_t next_child = node.child_base, tri_off = 0;
         uint8_t* qlo[3] = {node.qlox, node.qloy, node.qloz};
@@ -241,10 +283,10 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
                 q.push_back({c, next_child++, w.depth + 1});
                 sah += (double)cn.box.area() / root_area;
             } else {
-                uint32_t unary = cn.count == 1 ? 1u : (cn.count == 2 ? 3u : 7u);
+                const uint32_t n_rec = emit_leaf_records(tris, &B.order[cn.first], cn.count, out_tris, out_leaves); // 1 .. MQ_BVH_LEAF records
+                uint32_t unary = n_rec == 1 ? 1u : (n_rec == 2 ? 3u : 7u);
                 node.meta[s] = (uint8_t)((unary << 5) | tri_off);
-                for (uint32_t k = 0; k < cn.count; k++) out_tris.push_back(tris[B.order[cn.first + k]]);
-                tri_off += cn.count;
+                tri_off += n_rec;
                 sah += (double)cn.box.area() / root_area * cn.count;
             }
         }

@@ -102,7 +102,7 @@ struct MqProps {
     bool quirk_n16_wrap = true;    // mc.glsl:26 `N * N` on a uint16_t (grid.h:19): wraps, 0 at N = 256 / 512 / 768 / 1024
 };
 
-bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, float* sah_cost, std::string& err, uint32_t* depth_out = nullptr);
+bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, std::vector<MqLeafRec>& out_leaves, float* sah_cost, std::string& err, uint32_t* depth_out = nullptr);
 
 struct mq_ctx;
 bool mq_synth_generate(mq_ctx* ctx, const char* name, uint32_t seed, std::string& err);

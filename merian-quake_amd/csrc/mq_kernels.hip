@@ -30,7 +30,7 @@
 #define MQ_OCC_SHADE 2
 #endif
 #ifndef MQ_OCC_TRACE
-#define MQ_OCC_TRACE 6
+#define MQ_OCC_TRACE 5
 #endif
 
 struct RayHit { uint32_t tri; float t, u, v; };
@@ -333,24 +333,46 @@ MQ_DEV void trav_node(const MqSceneDev& sc, Trav& t, uint2* stk /* &lds[0][lane]
     trav_node_test(t, n0, n1, n2, n3, n4);
 }
 
-// Tests ONE pending triangle (lowest bit of t.tmask).
-template <bool COUNT>
-MQ_DEV void trav_tri(const MqSceneDev& sc, Trav& t, Ctr& ctr) {
-    uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
-    t.tmask &= t.tmask - 1u;
+// Tests ONE pending leaf record (lowest bit of t.tmask): one or two triangles that share an edge, as four vertices in four
+// 16-byte loads (MqLeafRec).  Both triangles in ONE loop step: measured with the old 48-byte records (two triangles per step,
+// six loads) the queue kernel took 8 % less time than with a step per triangle (profiles/r03_g_*).  TMIN / TMAX: the ray's
+// interval (visibility rays); the closest-hit queries pass (0, MQ_T_MAX): `tt > 0` is part of tri_isect already.
+struct LeafTris { f3 a0, a1, a2, b0, b1, b2; uint32_t key0, key1, tri0, sel; };
+MQ_DEV LeafTris load_leaf(const MqSceneDev& sc, uint32_t rec) {
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-    const u4v* tp = (const u4v*)(sc.tris + (t.tbase + k));
-    u4v a = tp[0], b = tp[1], c = tp[2];
-    // keep the record as three 16-byte loads (the vectoriser otherwise re-slices it into four overlapping ones)
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
-    if (COUNT) ctr.tris++;
+    const u4v* lp = (const u4v*)(sc.leaves + rec);
+    u4v r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3)); // four 16-byte loads, as written
+    LeafTris L;
+    const f3 v0 = F3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)), v1 = F3(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y));
+    const f3 v2 = F3(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), v3 = F3(__uint_as_float(r2.y), __uint_as_float(r2.z), __uint_as_float(r2.w));
+    L.a0 = v0; L.a1 = v1; L.a2 = v2; L.key0 = r3.x; L.key1 = r3.y; L.tri0 = r3.z; L.sel = r3.w;
+    L.b0 = v0; L.b1 = v2; L.b2 = v3; // the fan pattern (v0, v2, v3): nearly every record; anything else is selected below, wave-uniformly skipped when no lane needs it
+    if (__ballot((r3.w & MQ_LEAF_HAS_B) && (r3.w & 0x3fu) != MQ_LEAF_SEL_FAN) != 0ull) {
+        const uint32_t s0 = r3.w & 3u, s1 = (r3.w >> 2) & 3u, s2 = (r3.w >> 4) & 3u;
+        L.b0 = s0 == 0u ? v0 : (s0 == 1u ? v1 : (s0 == 2u ? v2 : v3));
+        L.b1 = s1 == 0u ? v0 : (s1 == 1u ? v1 : (s1 == 2u ? v2 : v3));
+        L.b2 = s2 == 0u ? v0 : (s2 == 1u ? v1 : (s2 == 2u ? v2 : v3));
+    }
+    return L;
+}
+template <bool COUNT>
+MQ_DEV void trav_tri(const MqSceneDev& sc, Trav& t, Ctr& ctr, float tmin = 0.0f, float tmax = MQ_T_MAX) {
+    const uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
+    t.tmask &= t.tmask - 1u;
+    const LeafTris L = load_leaf(sc, t.tbase + k);
+    if (COUNT) ctr.tris += (L.sel & MQ_LEAF_HAS_B) ? 2u : 1u;
     float tt = 0.0f, u = 0.0f, v = 0.0f;
-    bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)),
-                            F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
-                            F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), tt, u, v);
-    accept = accept && (tt < MQ_T_MAX) && (tt < t.hit.t || (tt == t.hit.t && c.y < t.best_key));
-    if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, t.tbase + k, u, v);
-    if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = t.tbase + k; t.best_key = c.y; t.tlim = trav_limit(tt); }
+    bool accept = tri_isect(t.o, t.d, L.a0, L.a1, L.a2, tt, u, v);
+    accept = accept && tt > tmin && tt < tmax && (tt < t.hit.t || (tt == t.hit.t && L.key0 < t.best_key));
+    if (accept && (L.sel & 0x10000u)) accept = anyhit_confirm(sc, L.tri0, u, v);
+    if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = L.tri0; t.best_key = L.key0; t.tlim = trav_limit(tt); }
+    if (L.sel & MQ_LEAF_HAS_B) {
+        accept = tri_isect(t.o, t.d, L.b0, L.b1, L.b2, tt, u, v);
+        accept = accept && tt > tmin && tt < tmax && (tt < t.hit.t || (tt == t.hit.t && L.key1 < t.best_key));
+        if (accept && (L.sel & 0x20000u)) accept = anyhit_confirm(sc, L.tri0 + 1u, u, v);
+        if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = L.tri0 + 1u; t.best_key = L.key1; t.tlim = trav_limit(tt); }
+    }
 }
 
 // After the pending triangles are done: continue with the current group or pop the stack.
@@ -391,18 +413,7 @@ MQ_DEV void traverse_range(const MqSceneDev& sc, f3 o, f3 d, float tmin, float t
     trav_defer(sc, t, stk);
     if (sc.n_nodes != 0) for (;;) {
         trav_node<COUNT>(sc, t, stk, spill, ctr);
-        while (t.tmask) { // trav_tri with the ray's own interval
-            const uint32_t k = (uint32_t)__ffs((int)t.tmask) - 1u;
-            t.tmask &= t.tmask - 1u;
-            const uint4* tp = (const uint4*)(sc.tris + (t.tbase + k));
-            const uint4 a = tp[0], b = tp[1], c = tp[2];
-            float tt = 0.0f, u = 0.0f, v = 0.0f;
-            bool accept = tri_isect(t.o, t.d, F3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)), F3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)),
-                                    F3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x)), tt, u, v);
-            accept = accept && tt > tmin && tt < tmax && (tt < t.hit.t || (tt == t.hit.t && c.y < t.best_key));
-            if (accept && (c.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, t.tbase + k, u, v);
-            if (accept) { t.hit.t = tt; t.hit.u = u; t.hit.v = v; t.hit.tri = t.tbase + k; t.best_key = c.y; t.tlim = trav_limit(tt); }
-        }
+        while (t.tmask) trav_tri<COUNT>(sc, t, ctr, tmin, tmax); // the ray's own interval
         if (trav_next(t, stk, spill)) break;
     }
     hit = t.hit;
@@ -1129,7 +1140,7 @@ MQ_DEV uint32_t pkt_node(const MqNode* nd, f3 o, f3 pn, int role, uint32_t child
     return wave_or(contrib);
 }
 
-__global__ __launch_bounds__(MQ_BLOCK, 7) void mq_primary_trace_kernel(MqSceneDev sc, MqFrame F, float fov_tan_alpha_half) {
+__global__ __launch_bounds__(MQ_BLOCK, 5) void mq_primary_trace_kernel(MqSceneDev sc, MqFrame F, float fov_tan_alpha_half) {
     __shared__ uint2 s_pstack[MQ_WAVES][MQ_PKT_STACK];   // the wave's shared stack of node groups
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint2* const pstk = &s_pstack[wave][0];
@@ -1180,19 +1191,23 @@ __global__ __launch_bounds__(MQ_BLOCK, 7) void mq_primary_trace_kernel(MqSceneDe
                 Gx = cbase; Gy = (hm & 0xff000000u) | imask;
                 uint32_t tmask = hm & 0x00ffffffu;
                 bool any_new = false;
-                while (tmask) { // every lane tests the triangle (one broadcast fetch) with its own ray: trav_tri's operations, acceptance rule and tie break
+                while (tmask) { // every lane tests the leaf record's triangles (one broadcast fetch) with its own ray: trav_tri's operations, acceptance rule and tie break
                     const uint32_t k = (uint32_t)__ffs((int)tmask) - 1u;
                     tmask &= tmask - 1u;
-                    const uint4* tp = (const uint4*)(sc.tris + (tbase + k));
-                    const uint4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    const LeafTris L = load_leaf(sc, tbase + k);
                     float tt = 0.0f, uu = 0.0f, vv = 0.0f;
-                    bool accept = tri_isect(o, d, F3(__uint_as_float(ta.x), __uint_as_float(ta.y), __uint_as_float(ta.z)),
-                                            F3(__uint_as_float(ta.w), __uint_as_float(tb.x), __uint_as_float(tb.y)),
-                                            F3(__uint_as_float(tb.z), __uint_as_float(tb.w), __uint_as_float(tc.x)), tt, uu, vv);
-                    accept = accept && (tt < MQ_T_MAX) && (tt < hit.t || (tt == hit.t && tc.y < best_key));
-                    if (accept && (tc.z & MQ_TRI_ANYHIT)) accept = anyhit_confirm(sc, tbase + k, uu, vv);
-                    if (accept) { hit.t = tt; hit.u = uu; hit.v = vv; hit.tri = tbase + k; best_key = tc.y; }
+                    bool accept = tri_isect(o, d, L.a0, L.a1, L.a2, tt, uu, vv);
+                    accept = accept && (tt < MQ_T_MAX) && (tt < hit.t || (tt == hit.t && L.key0 < best_key));
+                    if (accept && (L.sel & 0x10000u)) accept = anyhit_confirm(sc, L.tri0, uu, vv);
+                    if (accept) { hit.t = tt; hit.u = uu; hit.v = vv; hit.tri = L.tri0; best_key = L.key0; }
                     any_new = any_new || accept;
+                    if (L.sel & MQ_LEAF_HAS_B) { // (wave-uniform: every lane holds the same record)
+                        accept = tri_isect(o, d, L.b0, L.b1, L.b2, tt, uu, vv);
+                        accept = accept && (tt < MQ_T_MAX) && (tt < hit.t || (tt == hit.t && L.key1 < best_key));
+                        if (accept && (L.sel & 0x20000u)) accept = anyhit_confirm(sc, L.tri0 + 1u, uu, vv);
+                        if (accept) { hit.t = tt; hit.u = uu; hit.v = vv; hit.tri = L.tri0 + 1u; best_key = L.key1; }
+                        any_new = any_new || accept;
+                    }
                 }
                 if (__ballot(any_new) != 0ull) { // the farthest closest hit of the tile's (valid) rays bounds what is still worth visiting
                     const float m = wave_max_nonneg(valid ? fminf(hit.t, MQ_T_MAX) : 0.0f);
@@ -1335,7 +1350,7 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_SHADE) void mq_primary_kernel(MqSc
 #define MQ_REFILL_MIN 8u
 #endif
 #ifndef MQ_TRI_VOTE
-#define MQ_TRI_VOTE 16u
+#define MQ_TRI_VOTE 24u
 #endif
 #ifndef MQ_SHARE_MIN_IDLE
 #define MQ_SHARE_MIN_IDLE 8u // a hand-over round costs ~60 instructions of the whole wave: how many idle lanes make it worth it

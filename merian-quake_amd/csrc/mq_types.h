@@ -46,7 +46,7 @@ struct MqNode {
     float px, py, pz;          // quantisation origin
     uint8_t ex, ey, ez, imask; // per-axis scale exponent (biased), internal-child mask
     uint32_t child_base;       // index of first internal child
-    uint32_t tri_base;         // index of first triangle
+    uint32_t tri_base;         // index of the node's first leaf record (MqLeafRec)
     uint8_t meta[8];
     uint8_t qlox[8], qloy[8], qloz[8];
     uint8_t qhix[8], qhiy[8], qhiz[8];
@@ -63,6 +63,22 @@ struct MqTri {
 static_assert(sizeof(MqTri) == 48, "triangle must be 48 bytes");
 #define MQ_TRI_ANYHIT 1u
 #define MQ_TRI_DYNAMIC 2u
+
+// 64-byte LEAF RECORD of the traversal: one or two triangles that share an edge -- the two halves of a brush quad, two
+// neighbours of a polygon's fan -- as FOUR vertices instead of six.  A leaf slot of a node (one bit of its hit mask)
+// addresses one record: four 16-byte loads and one loop step for two triangle tests, where two 48-byte MqTri records cost six
+// loads and two steps.  Triangle A = (v[0], v[1], v[2]); triangle B = (v[s0], v[s1], v[s2]) with two-bit selectors: the
+// vertices keep the ORDER they have in the index buffer (the intersection arithmetic, and with it every bit of t, u, v, is
+// that of the uploaded triangle).  The MqTri / MqShadeRec arrays (shading) stay: A is triangle tri0 of them, B is tri0 + 1.
+struct MqLeafRec {
+    float v[4][3];
+    uint32_t key0, key1; // slot << 28 | prim of A and B (tie break of equal hit distances)
+    uint32_t tri0;
+    uint32_t sel;        // bits 0..5: s0 | s1 << 2 | s2 << 4; bit 8: B present; bit 16 / 17: A / B needs the any-hit alpha test
+};
+static_assert(sizeof(MqLeafRec) == 64, "leaf record must be 64 bytes");
+#define MQ_LEAF_HAS_B 0x100u
+#define MQ_LEAF_SEL_FAN 0x38u // B = (v0, v2, v3): the second triangle of a quad (a, b, c)(a, c, d) or of a fan -- nearly every record
 
 struct MqTexDesc {
     uint32_t offset; // texel offset into the texel pool; MQ_NIL if the slot is empty
@@ -173,6 +189,7 @@ struct MqGeoDev {
 struct MqSceneDev {
     const MqNode* nodes;
     const MqTri* tris;
+    const MqLeafRec* leaves; // the traversal's leaf records (MqNode::tri_base counts these)
     const MqShadeRec* shade; // one per triangle, same order as tris
     MqGeoDev geo[MQ_MAX_GEOMETRIES];
     const MqTexDesc* tex;

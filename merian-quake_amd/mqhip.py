@@ -30,7 +30,8 @@ assert EXT_DTYPE.itemsize == 28
 NODE_DTYPE = np.dtype([("p", "<f4", (3,)), ("e", "u1", (3,)), ("imask", "u1"), ("child_base", "<u4"), ("tri_base", "<u4"),
                        ("meta", "u1", (8,)), ("qlo", "u1", (3, 8)), ("qhi", "u1", (3, 8))])
 TRI_DTYPE = np.dtype([("v", "<f4", (3, 3)), ("key", "<u4"), ("flags", "<u4"), ("pad", "<u4")])
-assert NODE_DTYPE.itemsize == 80 and TRI_DTYPE.itemsize == 48
+LEAF_DTYPE = np.dtype([("v", "<f4", (4, 3)), ("key0", "<u4"), ("key1", "<u4"), ("tri0", "<u4"), ("sel", "<u4")])  # MqLeafRec: one or two triangles sharing an edge
+assert NODE_DTYPE.itemsize == 80 and TRI_DTYPE.itemsize == 48 and LEAF_DTYPE.itemsize == 64
 
 
 class Uniform(C.Structure):
@@ -136,6 +137,7 @@ def load_library(path=None):
         "mq_timing_detail_frames": (i32, [P, C.POINTER(C.c_uint32)]),
         "mq_scene_layout": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mq_scene_commit_counts": (i32, [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "mq_scene_get_leaves": (i32, [P, C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "mq_scene_stats": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]),
         "mq_describe": (i32, [P, u32, u32, C.POINTER(IoDesc)]),
         "mq_connect": (i32, [P, u32, u32]),
@@ -310,6 +312,12 @@ class Context:
         nodes = np.frombuffer((C.c_char * (nn.value * 80)).from_address(n.value), dtype=NODE_DTYPE).copy() if nn.value else np.empty(0, NODE_DTYPE)
         tris = np.frombuffer((C.c_char * (nt.value * 48)).from_address(t.value), dtype=TRI_DTYPE).copy() if nt.value else np.empty(0, TRI_DTYPE)
         return nodes, tris
+
+    def get_leaves(self):
+        """the traversal's 64-byte leaf records (a node's tri_base / meta offsets count these)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.mq_scene_get_leaves(self.h, C.byref(p), C.byref(n)))
+        return np.frombuffer((C.c_char * (n.value * 64)).from_address(p.value), dtype=LEAF_DTYPE).copy() if n.value else np.empty(0, LEAF_DTYPE)
 
     def scene_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

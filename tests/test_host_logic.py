@@ -144,8 +144,10 @@ def _decode_children(node):
     return lo, hi
 
 
-def _walk_bvh(nodes, tris, root=0):
-    """Checks the structural invariants below `root`; returns the sets of nodes and triangles reached."""
+def _walk_bvh(nodes, tris, root=0, leaves=None):
+    """Checks the structural invariants below `root`; returns the sets of nodes and triangles reached.  A leaf slot addresses
+    1..3 LEAF RECORDS (one or two triangles that share an edge, as four vertices): the record's triangles must be the
+    triangle array's tri0 / tri0 + 1, vertex for vertex in their own order."""
     seen_nodes, seen_tris = set(), set()
     stack = [(root, None, None)]
     while stack:
@@ -170,11 +172,19 @@ def _walk_bvh(nodes, tris, root=0):
             else:
                 cnt = {1: 1, 3: 2, 7: 3}[m >> 5]
                 first = int(node["tri_base"]) + (m & 31)
-                for t in range(first, first + cnt):
-                    assert t not in seen_tris
-                    seen_tris.add(t)
-                    v = tris[t]["v"]
-                    assert (v.min(0) >= clo).all() and (v.max(0) <= chi).all()  # conservative quantised boxes
+                for rec in range(first, first + cnt):
+                    L = leaves[rec]
+                    sel = int(L["sel"])
+                    members = [(int(L["tri0"]), L["v"][:3], int(L["key0"]), bool(sel & 0x10000))]
+                    if sel & 0x100:
+                        members.append((int(L["tri0"]) + 1, L["v"][[sel & 3, (sel >> 2) & 3, (sel >> 4) & 3]], int(L["key1"]), bool(sel & 0x20000)))
+                    else:
+                        assert int(L["key1"]) == 0xffffffff
+                    for t, v, key, anyhit in members:
+                        assert t not in seen_tris
+                        seen_tris.add(t)
+                        assert v.tobytes() == tris[t]["v"].tobytes() and key == int(tris[t]["key"]) and anyhit == bool(int(tris[t]["flags"]) & 1)
+                        assert (v.min(0) >= clo).all() and (v.max(0) <= chi).all()  # conservative quantised boxes
     return seen_nodes, seen_tris
 
 
@@ -183,18 +193,21 @@ def test_cwbvh_invariants(mq):
     ctx.synth_scene("synth_tiny", 2)
     ctx.commit()
     nodes, tris = ctx.get_bvh()
+    leaves = ctx.get_leaves()
     total = sum(len(ctx.get_geometry(s)["idx"]) for s in range(3) if ctx.get_geometry(s) is not None)
     assert len(tris) == total
     assert len(np.unique(tris["key"])) == total  # every triangle exactly once
-    seen_nodes, seen_tris = _walk_bvh(nodes, tris)
+    assert total / 2 <= len(leaves) <= total and ((leaves["sel"] & 0x100) != 0).sum() == total - len(leaves)
+    assert ((leaves["sel"] & 0x13f) == 0x138).mean() > 0.5  # mostly quads: the second triangle is (v0, v2, v3)
+    seen_nodes, seen_tris = _walk_bvh(nodes, tris, 0, leaves)
     n_s = ctx.scene_layout()[0]
     if n_s < len(nodes):  # the per-frame tree has its own root behind the static tree
-        more = _walk_bvh(nodes, tris, n_s)
+        more = _walk_bvh(nodes, tris, n_s, leaves)
         assert not (seen_nodes & more[0]) and not (seen_tris & more[1])
         seen_nodes |= more[0]; seen_tris |= more[1]
     assert len(seen_nodes) == len(nodes) and len(seen_tris) == len(tris)
     st = ctx.scene_stats()
-    assert st["bvh_bytes"] == len(nodes) * 80 + len(tris) * 48
+    assert st["bvh_bytes"] == len(nodes) * 80 + len(leaves) * 64
 
 
 def test_static_and_per_frame_trees(mq):
@@ -216,8 +229,9 @@ def test_static_and_per_frame_trees(mq):
         nodes, tris = ctx.get_bvh()
         assert len(tris) == n_static + n_tri and ctx.scene_layout() == (len(nodes0), n_static)
         assert nodes[:len(nodes0)].tobytes() == nodes0.tobytes() and tris[:n_static].tobytes() == tris0.tobytes()
-        s_nodes, s_tris = _walk_bvh(nodes, tris, 0)
-        d_nodes, d_tris = _walk_bvh(nodes, tris, len(nodes0))  # the per-frame root
+        leaves = ctx.get_leaves()
+        s_nodes, s_tris = _walk_bvh(nodes, tris, 0, leaves)
+        d_nodes, d_tris = _walk_bvh(nodes, tris, len(nodes0), leaves)  # the per-frame root
         assert s_nodes == set(range(len(nodes0))) and d_nodes == set(range(len(nodes0), len(nodes)))
         assert s_tris == set(range(n_static)) and d_tris == set(range(n_static, n_static + n_tri))
         assert ((tris["key"][n_static:] >> 28) == 4).all() and (tris["flags"][n_static:] & 2).all()  # distinct previous positions
