@@ -431,7 +431,7 @@ def main():
     roofline = {"bound": "l1-gather+valu", "contract_bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "hbm_measured": hbm_measured,
                 "limiter": "L1 gather path (TA/TD busy) and VALU issue; measured HBM traffic is far below the algorithmic bytes (L2 / Infinity Cache hits)", "kernel": dom,
-                "overlap": ("none" if ctx.get_property("overlap camera rays") == 0 else "the camera rays of frame n+1 run on a low-priority stream beside the update pass of frame n (a full frame) or beside its last round too (a rank of a "
+                "overlap": ("none" if ctx.get_property("overlap camera rays") == 0 else "the camera rays of frame n+1 run on a low-priority stream beside the terminal bounce kernel and the update pass of frame n (a full frame) or beside its whole last round (a rank of a "
                             "partitioned frame): property \"overlap camera rays\"; the intervals below are those of the launch stream"),
                 "achievable_peak": round(ctx.measure_stream_read(), 1),  # streaming read of 2 GiB on this GPU, GB/s (the 8 TB/s above is the spec figure)
                 "kernel_ms_per_launch": round(dom_ms_per_launch, 4), "launches_per_frame": launches[dom], "kernel_timed_frames": n_detail,

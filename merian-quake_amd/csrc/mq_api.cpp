@@ -288,7 +288,7 @@ const PropDesc k_props[] = {
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
-    {"overlap camera rays", PT_OPTION, POFF(overlap_camera_rays), false, {"off", "auto", "always", "update pass", "last round"}},
+    {"overlap camera rays", PT_OPTION, POFF(overlap_camera_rays), false, {"off", "auto", "always", "update pass", "last round", "last bounce"}},
     {"camera rays: frustum packets", PT_BOOL, POFF(packet_camera_rays), false, {}},
     // named quirk switches of this build (SURVEY Appendix D.4 / mc.glsl:26 uint16 arithmetic)
     {"quirk: LC max(wo_p,10)", PT_BOOL, POFF(quirk_lc_max_wo_p), false, {}},
@@ -1177,10 +1177,14 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     // last round 1.93 / 1.10 / 0.66 / 0.46 ms.  "auto": last round for a rank of a partitioned frame; update pass for a full
     // frame, where it keeps every kernel of the surface pass alone on the chip (their times stay those of the kernels) for
     // 3 % of the frame time.
-    const int mode = ov == 1 ? (c->world > 1 ? 4 : 3) : ov;
-    const bool behind_bounces = mode == 3 || mode == 4;
+    // Round 3: "last bounce" = behind the last TRACE launch, i.e. beside the terminal bounce kernel and the update pass only.  That kernel
+    // waits for scattered gathers (TD busy 0.86, vector ALU 0.57) and the camera rays are pure ALU work: on a full frame it loses 2 us
+    // (0.150 -> 0.152 ms) while the frame gains 0.05 ms (1.93 -> 1.88 ms, profiles/r03_o_camera_ray_start.txt), and every trace launch
+    // still has the chip to itself -- which "last round" (1.875 ms) gives up.  "auto" for a full frame since then.
+    const int mode = ov == 1 ? (c->world > 1 ? 4 : 5) : ov;
+    const bool behind_bounces = mode == 3 || mode == 4 || mode == 5;
     static const int pt_behind_env = getenv("MQ_DEBUG_PT_BEHIND") ? atoi(getenv("MQ_DEBUG_PT_BEHIND")) : -1; // tuning experiments only
-    const int pt_behind = std::min(std::max(pt_behind_env >= 0 ? pt_behind_env : (mode == 3 ? 0 : 2), 0), std::max(0, 2 * rounds - 1));
+    const int pt_behind = std::min(std::max(pt_behind_env >= 0 ? pt_behind_env : (mode == 3 ? 0 : (mode == 5 ? 1 : 2)), 0), std::max(0, 2 * rounds - 1));
     const uint32_t parity = c->frame_parity & 1u;
     c->ev_pt_timed[slot] = overlap_pt && detail;
     if (overlap_pt) {

@@ -78,8 +78,8 @@ struct MqProps {
     bool lc_lock_statistics = false; // the reference's light-cache try-lock with per-cell counters + last_update_count per slot (for the state dumps)
     int overlap_camera_rays = 1;      // scheduling of this build: the camera rays of frame n + 1 traced beside kernels of frame n, on a low-priority stream
                                       // with its own hardware queue.  0 off; 2 always: from the start of frame n; 3 update pass: beside frame n's link /
-                                      // apply kernels only; 4 last round: from frame n's last trace launch on; 1 auto: 4 for a rank of a partitioned frame,
-                                      // 3 for a full frame.  Measurements: mq_process in mq_api.cpp
+                                      // apply kernels only; 4 last round: from frame n's last trace launch on; 5 last bounce: beside frame n's terminal bounce kernel and
+                                      // its update pass; 1 auto: 4 for a rank of a partitioned frame, 5 for a full frame.  Measurements: mq_process in mq_api.cpp
     bool packet_camera_rays = false;  // scheduling of this build: camera rays as one frustum packet per 8x8 tile (bit-identical; measured slower than the per-lane walk)
     int pipelines = 1; // scheduling of this build, not a reference property: sub-pipelines per frame (mq_api.cpp mq_process)
     bool sequential_update_pass = false; // test hook: the update pass in the reference's dispatch order, one slot after the other

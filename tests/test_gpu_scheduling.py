@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 SMALL = {"adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16}
-SETTINGS = [(1, "off"), (2, "off"), (4, "off"), (1, "always"), (3, "always"), (1, "update pass"), (2, "auto"), (1, "last round")]
+SETTINGS = [(1, "off"), (2, "off"), (4, "off"), (1, "always"), (3, "always"), (1, "update pass"), (2, "auto"), (1, "last round"), (1, "last bounce")]
 
 
 def _outputs(ctx):
