@@ -97,7 +97,7 @@ struct mq_ctx {
     int restir_occ[4] = {0, 0, 0, 0}; // resident blocks per CU of the ReSTIR pass kernels
     bool queues_dirty = true;      // the ray-queue control words have to be zeroed before the next frame uses them
     DevBuf d_paths, d_rays, d_ray_hits, d_qslots[2], d_debug_rng;
-    DevBuf d_prev_vdepth, d_dist_mc;
+    DevBuf d_prev_vdepth, d_dist_mc, d_fp_winner;
     DevBuf d_restir_pong, d_restir_prev, d_restir_prev_gb; // ReSTIR: ping-pong partner of the "reservoirs" output, last frame's reservoirs and g-buffer (the graph's delay-1 inputs)
     uint64_t restir_iteration = 0; bool restir_seeded = false; uint32_t restir_seed_in_use = 0;
     DevBuf d_post_prev_gb, d_post_prev_out[2], d_post_prev_hist[2]; // post chain: last frame's g-buffer, accumulated images and histories (surface, volume)
@@ -413,7 +413,7 @@ void free_frame_state(mq_ctx* c) {
     dev_free(c->d_ctrl); dev_free(c->d_counters); dev_free(c->d_spill);
     dev_free(c->d_restir_pong); dev_free(c->d_restir_prev); dev_free(c->d_restir_prev_gb);
     dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
-    dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0; dev_free(c->d_lc_stats); dev_free(c->d_last_upd);
+    dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_fp_winner); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0; dev_free(c->d_lc_stats); dev_free(c->d_last_upd);
     dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); dev_free(c->d_band_hits); c->shaded_valid[0] = c->shaded_valid[1] = false; c->bounced_valid = false;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
@@ -959,6 +959,8 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_qslots[1], (size_t)c->ray_cap * 4))) return r;
     if ((r = dev_alloc(c, c->d_prev_vdepth, (size_t)w * h * 2))) return r;
     HIPCHK(c, hipMemset(c->d_prev_vdepth.p, 0, c->d_prev_vdepth.bytes));
+    if ((r = dev_alloc(c, c->d_fp_winner, (size_t)w * h * 4))) return r;
+    HIPCHK(c, hipMemset(c->d_fp_winner.p, 0, c->d_fp_winner.bytes)); // (the resolve pass leaves it zero again)
     if ((r = dev_alloc(c, c->d_post_prev_gb, (size_t)w * h * 16))) return r;
     for (int k = 0; k < 2; k++) { if ((r = dev_alloc(c, c->d_post_prev_out[k], (size_t)w * h * 16))) return r; if ((r = dev_alloc(c, c->d_post_prev_hist[k], (size_t)w * h * 4))) return r; }
     c->post_first = true;
@@ -1035,7 +1037,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
         if (div > 1) F.ray_cap = std::max(1024u, F.ray_cap / (uint32_t)div);
     }
     F.volume = (float*)c->d_out[MQ_OUT_VOLUME].p; F.volume_depth = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH].p; F.volume_mv = (uint16_t*)c->d_out[MQ_OUT_VOLUME_MV].p;
-    F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
+    F.prev_volume_depth = (uint16_t*)c->d_prev_vdepth.p; F.fp_winner = (uint32_t*)c->d_fp_winner.p; F.dist_mc = (float4*)c->d_dist_mc.p; F.dist_mc_n = c->dist_mc_n;
     F.lc_stats = (uint2*)c->d_lc_stats.p; F.last_upd_count = (uint32_t*)c->d_last_upd.p;
     F.learn_log = (uint4*)c->d_learn_log.p; F.learn_log_count = (uint32_t*)c->d_learn_count.p; F.learn_log_cap = c->learn_log_cap;
     const int K = c->params.reference_mode ? 0 : std::max(0, c->params.mc_samples);

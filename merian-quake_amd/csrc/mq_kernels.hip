@@ -1709,7 +1709,12 @@ MQ_DEV MqDistMC distance_mc_load(const MqFrame& F, uint32_t i) {
     return s;
 }
 
-__global__ void mq_forward_project_kernel(MqParams P, MqFrame F) { // volume_forward_project.comp:17-53
+// volume_forward_project.comp:17-53 is a SCATTER: every pixel projects last frame's scatter point into this frame and writes
+// `pixel - target` at the target; pixels that collide race (the reference does not order them either).  Here the collisions are
+// resolved: pass 1 keeps, per target, the LARGEST linear index of the pixels that hit it (one atomicMax), pass 2 writes that
+// pixel's vector -- the image a sequential row-major sweep leaves (the last writer wins), i.e. the oracle's, bit for bit, so
+// that the guided volume estimator, whose distance lookups read `volume_mv`, is deterministic with forward projection ON too.
+__global__ void mq_forward_project_kernel(MqParams P, MqFrame F) {
     const mq_uniform& U = F.u;
     const float Wf = (float)F.W, Hf = (float)F.H;
     const uint32_t total = F.n_local_tiles * 64u;
@@ -1725,8 +1730,17 @@ __global__ void mq_forward_project_kernel(MqParams P, MqFrame F) { // volume_for
         float rx = floorf(fx + 0.5f), ry = floorf(fy + 0.5f);
         if (!(rx >= 0.0f && ry >= 0.0f && rx < Wf && ry < Hf)) continue;
         if (prev_depth < 50.0f) continue;
-        size_t o = (size_t)(int)ry * F.W + (size_t)(int)rx;
-        *(uint32_t*)(F.volume_mv + 2 * o) = (uint32_t)f2h((float)px - rx) | ((uint32_t)f2h((float)py - ry) << 16);
+        atomicMax(&F.fp_winner[(size_t)(int)ry * F.W + (size_t)(int)rx], py * F.W + px + 1u);
+    }
+}
+__global__ void mq_forward_project_resolve_kernel(MqFrame F) { // every pixel: a rank of a partitioned frame scatters from its own pixels only, but onto any target
+    const size_t n = (size_t)F.W * F.H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t w = F.fp_winner[i];
+        if (w == 0u) continue;
+        F.fp_winner[i] = 0u; // ready for the next frame
+        const uint32_t src = w - 1u, sx = src % F.W, sy = src / F.W, tx = (uint32_t)(i % F.W), ty = (uint32_t)(i / F.W);
+        *(uint32_t*)(F.volume_mv + 2 * i) = (uint32_t)f2h((float)sx - (float)tx) | ((uint32_t)f2h((float)sy - (float)ty) << 16);
     }
 }
 
@@ -2272,6 +2286,7 @@ int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int 
 }
 int mq_launch_forward_project(const MqParams& P, const MqFrame& F, int grid, hipStream_t s) {
     mq_forward_project_kernel<<<grid, 256, 0, s>>>(P, F);
+    mq_forward_project_resolve_kernel<<<grid, 256, 0, s>>>(F);
     return (int)hipGetLastError();
 }
 int mq_launch_volume_sample(const MqSceneDev& sc, const MqParams& P, const MqFrame& F, int smp, int round, bool count, int grid, hipStream_t s) {

@@ -236,6 +236,7 @@ struct MqFrame {
     uint16_t* volume_depth;      // W*H half (volume.comp:211)
     uint16_t* prev_volume_depth; // W*H half: last frame's volume_depth (delay-1 feedback)
     uint16_t* volume_mv;   // W*H*2 half
+    uint32_t* fp_winner;   // W*H: forward projection, per TARGET pixel the largest linear index + 1 of the pixels that project onto it (0: none)
     float4* dist_mc;       // distance Markov chains: (sum_w, N, m0, m1) per state, 10 states per grid vertex
     uint32_t dist_mc_n;
     // learning state

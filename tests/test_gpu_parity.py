@@ -689,7 +689,7 @@ def test_volume_pass_deterministic_parity(gpu_ctx):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
         assert np.array_equal(ctx.read_output(mqhip.OUT_VOLUME_DEPTH), o.output(orc.OUT_VOLUME_DEPTH))
         a, b = ctx.read_output(mqhip.OUT_VOLUME_MV).view(np.uint32), o.output(orc.OUT_VOLUME_MV).view(np.uint32)
-        assert (a == b).mean() > 0.97  # forward projection scatters: colliding writers may resolve differently
+        assert np.array_equal(a, b)  # forward projection scatters; colliding writers are resolved as a row-major sweep leaves them (round 3)
         # the surface pass is unaffected by the volume pass
         assert np.array_equal(ctx.irradiance().view(np.uint32), o.irradiance().view(np.uint32))
         lit += ref[..., :3].sum()
