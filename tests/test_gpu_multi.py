@@ -219,3 +219,21 @@ def test_bench_restir_two_ranks_rehearsed_on_one_gpu(mqlib):
     assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-500:])
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["backend"] == "gloo" and "halo rows" in line["config"]["collective"] and line["value"] > 0
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_bench_two_ranks_rehearsed_on_one_gpu(mqlib, mode):
+    """`python bench.py --gpus 2` end to end -- self-launch of the ranks, tile partition, exchange (mode 1: in line; mode 2: on the
+    side stream, overlapped with the next frame, with bench.py's own check that the assembled image holds the rank's tiles),
+    MAX all-reduce of the time, rank 0's line with the CPU baseline (every N carries it) -- with both ranks on this box's one GPU
+    and the exchange staged through gloo (`MQ_BENCH_REHEARSAL_ONE_GPU`; never a measurement)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MQ_BENCH_REHEARSAL_ONE_GPU=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--width", "320", "--height", "200",
+                        "--scene", "synth_start", "--scene-seed", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-500:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["backend"] == "gloo" and line["value"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    assert ("overlapped" in line["config"]["collective"]) == (mode == "2")
