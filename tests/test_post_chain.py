@@ -106,8 +106,8 @@ def gpu_pair(ctx, scene, seed, props, W, H):
     return oracle_for(ctx, W, H)
 
 
-# forward projection off: it scatters (colliding writers may resolve differently on the device), volume_mv is then the copy of gbuffer.mv (render_mcpg.cpp:284-288)
-VOLDET = {"volume spp": 2, "particle size": 7.0, "volume: use LC": 1, "dist guide p": 0.9, "Phase Prob": 0.1, "mc samples": 0, "dist mc samples": 0, "volume forward project": 0}
+# (forward projection on: its scatter is resolved deterministically since round 3, `volume accum` follows the projected vectors on both sides)
+VOLDET = {"volume spp": 2, "particle size": 7.0, "volume: use LC": 1, "dist guide p": 0.9, "Phase Prob": 0.1, "mc samples": 0, "dist mc samples": 0, "volume forward project": 1}
 
 
 @pytest.mark.gpu
@@ -196,3 +196,31 @@ def test_convergence_curve_guided_vs_unguided(gpu_ctx):
     # (a BSDF-branch sample that finds the lamp is weighted 1 / "BSDF Prob") -- and is reported, not asserted
     assert med["guided"][-1] < 0.65 * med["unguided"][-1], med
     assert all(g < u for g, u in zip(med["guided"][3:], med["unguided"][3:])), med
+
+
+@pytest.mark.gpu
+def test_add_node_takes_the_restir_irradiance(gpu_ctx):
+    """BASELINE config 5, "ReSTIR DI + MCPG GI combined": with `"add: restir irradiance"` the composition adds the ReSTIR node's
+    irradiance, re-modulated with the albedo like the MCPG irradiance (one more input of the graph's `add` node,
+    res/default_config.json:429-435; DEFINED by this build like the rest of the post chain).  MCPG + ReSTIR node + post chain
+    over a moving camera: the final image bit-identical to the oracle, and different from the one without the input."""
+    import mqhip
+    ctx = gpu_ctx
+    W, H = 160, 96
+    o = gpu_pair(ctx, "synth_start", 5, {"reference mode": 1, "spp": 1, "restir: randomize seed": 0, "restir: seed": 77, "restir: spp": 2,
+                                         "restir: enable temporal reuse": 1, "restir: spatial reuse iterations": 1, "add: restir irradiance": 1}, W, H)
+    rp = orc.restir_params_from_ctx(ctx)
+    for f in range(4):
+        u = ctx.synth_camera(f * 3)
+        ctx.process(u); ctx.restir_process(u); ctx.post_process()
+        o.process(u, threads=8); o.restir_process(rp, u, threads=8); o.post_process()
+        a = ctx.read_output(mqhip.OUT_FINAL).view(np.uint32); b = o.post_output(o.POST_FINAL).view(np.uint32).reshape(-1)
+        assert np.array_equal(a, b), "frame %d: %d values differ" % (f, (a != b).sum())
+    with_direct = ctx.image(mqhip.OUT_FINAL).copy()
+    accum = ctx.image(mqhip.OUT_ACCUM); direct = ctx.image(mqhip.OUT_RESTIR_IRRADIANCE)
+    albedo = ctx.read_output(mqhip.OUT_GB_ALBEDO).view(np.float16).reshape(H, W, 4).astype(np.float32)
+    emis = ctx.read_output(mqhip.OUT_GB_IRRADIANCE).view(np.float16).reshape(H, W, 4).astype(np.float32)
+    base = (accum[..., :3] * albedo[..., :3] + ctx.image(mqhip.OUT_VOLUME_ACCUM)[..., :3]) + emis[..., :3]
+    assert np.array_equal(with_direct[..., :3], base + direct[..., :3] * albedo[..., :3]) and (direct[..., :3] * albedo[..., :3]).sum() > 0
+    ctx.set_property("add: restir irradiance", 0)
+    o.close()
