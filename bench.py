@@ -238,7 +238,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     tiles, tile_bytes = ctx.tiles_per_rank()
     tiles_ptr, _ = ctx.map_output(mqhip.OUT_TILES)
-    local = gathered = vlocal = vgathered = None
+    local = gathered = vlocal = vgathered = dlocal = dgathered = None
     side = staging = vstaging = image = vimage = None
     # The exchange of frame N overlaps the rendering of frame N + 1: tiles are copied to a staging buffer on the
     # render stream, the RCCL all-gather and the un-tiling into a bench-owned image run on a side stream.
@@ -252,6 +252,10 @@ def main():
             vptr, _ = ctx.map_output(mqhip.OUT_VOLUME_TILES)
             vlocal = torch.as_tensor(_DevArray(vptr, tile_bytes // 4), device="cuda")
             vgathered = torch.empty(world * (tile_bytes // 4), dtype=torch.float32, device="cuda")
+            if ctx.get_property("volume forward project"):  # the projection scatters from every pixel of last frame's volume_depth: a third, small exchange (2 B/pixel; passed around as float32 words)
+                dptr, dbytes = ctx.map_output(mqhip.OUT_VOLUME_DEPTH_TILES)
+                dlocal = torch.as_tensor(_DevArray(dptr, dbytes // 4), device="cuda")
+                dgathered = torch.empty(world * (dbytes // 4), dtype=torch.float32, device="cuda")
         if overlap:
             side = torch.cuda.Stream()
             staging = torch.empty_like(local)
@@ -316,6 +320,8 @@ def main():
             gather_sync(gathered, local, ctx.untile)
             if vlocal is not None:
                 gather_sync(vgathered, vlocal, ctx.untile_volume)
+            if dlocal is not None:
+                gather_sync(dgathered, dlocal, ctx.untile_volume_depth)
             if args.restir:
                 restir_and_post(u)
             return
@@ -324,6 +330,8 @@ def main():
         staging.copy_(local)
         if vlocal is not None:
             vstaging.copy_(vlocal)
+        if dlocal is not None:  # (needed by the NEXT frame's projection: in line, it is 1 / 8 of the radiance exchange)
+            gather_sync(dgathered, dlocal, ctx.untile_volume_depth)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             for dst, src, img in ((gathered, staging, image), (vgathered, vstaging, vimage)):
@@ -450,7 +458,7 @@ def main():
                                      W, H, args.spp, "off (reference mode)" if args.reference_mode else "on",
                                      " + ReSTIR DI node (1 candidate, temporal + spatial reuse) + accumulate / compose (config 5)" if args.restir else ""),
                       **({"properties_changed": extra} if extra else {}), "triangles": stats["n_tris"], "bvh_nodes": stats["n_nodes"], "parallelism": "tiles%d" % world, "ranks": world, "backend": (dist.get_backend() if exchange else "none"),
-                      "collective": "none" if not exchange else "%dx RCCL all_gather of %d B/rank per frame%s%s" % (2 if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "",
+                      "collective": "none" if not exchange else "%dx RCCL all_gather of %d B/rank per frame%s%s" % ((3 if dlocal is not None else 2) if args.volume_spp > 0 else 1, tile_bytes, ", overlapped with the next frame" if overlap else "",
                                     "" if not args.restir else "; row bands for the ReSTIR node / post chain: point-to-point halo rows, %d B received per frame by rank 0, + all_gather of the final image's rows (%d B/rank)"
                                     % (halo_recv_bytes, max(b.row_end - b.row_begin for b in bands) * W * 16))},
            "roofline": roofline}

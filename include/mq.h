@@ -105,6 +105,8 @@ enum {
     MQ_OUT_RESTIR_IRRADIANCE = 17,    /* "irradiance" RGBA32F (direct light at the first hit, albedo excluded; a = 1) */
     MQ_OUT_RESTIR_MOMENTS = 18,       /* "moments" RG32F: luminance, luminance^2 */
     MQ_OUT_RESTIR_RESERVOIRS = 19,    /* "reservoirs": 64 B/pixel ReSTIRDIReservoir, res/shader/render_restir/restir_di_reservoir.glsl.h:8-27 */
+    MQ_OUT_VOLUME_DEPTH_TILES = 20,   /* this rank's "volume_depth" tiles, tile-major R16F (third exchange buffer: configs with volume spp > 0 AND "volume forward project",
+                                       * whose scatter reads last frame's volume_depth of EVERY pixel, render_mcpg.cpp:296-311) */
     MQ_OUT_COUNT
 };
 
@@ -290,6 +292,9 @@ int mq_untile(mq_ctx* ctx, const void* gathered_dev, void* stream);
 int mq_untile_to(mq_ctx* ctx, const void* gathered_dev, void* image_dev, void* stream);
 /* the same for the gathered MQ_OUT_VOLUME_TILES buffers -> MQ_OUT_VOLUME */
 int mq_untile_volume(mq_ctx* ctx, const void* gathered_dev, void* stream);
+/* ... and for the gathered MQ_OUT_VOLUME_DEPTH_TILES buffers -> MQ_OUT_VOLUME_DEPTH: with it every rank forward-projects from ALL pixels of
+ * the last frame, as one rank does (without it a rank projects from its own pixels only: an approximation) */
+int mq_untile_volume_depth(mq_ctx* ctx, const void* gathered_dev, void* stream);
 
 /* ---- row partition of the ReSTIR DI node and the post chain (no reference counterpart; BASELINE config 5 on N GPUs) ----
  * Temporal reuse, spatial reuse and temporal accumulation read OTHER pixels (the reprojected one, neighbours within the spatial

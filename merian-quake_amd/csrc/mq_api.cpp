@@ -35,6 +35,7 @@ int mq_launch_stream_read(const void* src, size_t bytes, uint32_t* sink, int gri
 int mq_resident_blocks(bool guided, size_t shade_lds_bytes, int shade_block, int out[4]);
 int mq_launch_clear(const MqFrame& F, hipStream_t s);
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
+int mq_launch_untile16(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s);
 int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s);
 int mq_launch_math(const MqSceneDev& sc, const MqParams& P, int op, int ni, int no, const float* in, float* out, uint32_t n, hipStream_t s);
 int mq_launch_forward_project(const MqParams& P, const MqFrame& F, int grid, hipStream_t s);
@@ -451,7 +452,7 @@ BandRows band_rows(const MqProps& q, uint32_t H, int rank, int world, int radius
     return b;
 }
 
-const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8, 16, 4, 16, 4, 16, 16, 8, 64};
+const uint32_t k_bpp[MQ_OUT_COUNT] = {16, 8, 8, 4, 16, 40, 16, 16, 2, 4, 16, 8, 16, 4, 16, 4, 16, 16, 8, 64, 2};
 
 void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     memset(d, 0, sizeof *d);
@@ -462,6 +463,7 @@ void fill_desc(const mq_ctx* c, uint32_t w, uint32_t h, mq_io_desc* d) {
     for (int i = 0; i < MQ_OUT_COUNT; i++) { d->bytes_per_pixel[i] = k_bpp[i]; d->bytes[i] = px * k_bpp[i]; }
     d->bytes[MQ_OUT_TILES] = (size_t)tpr * 64 * 16;
     d->bytes[MQ_OUT_VOLUME_TILES] = (size_t)tpr * 64 * 16;
+    d->bytes[MQ_OUT_VOLUME_DEPTH_TILES] = (size_t)tpr * 64 * 2;
     size_t mc_total = (size_t)c->props.mc_adaptive_buffer_size + c->props.mc_static_buffer_size; // render_mcpg.cpp:59
     d->state_bytes_markovchain = mc_total * sizeof(MqMCState) + mc_total * 8; // states + per-slot count and chain head of the update queue
     d->state_bytes_lightcache = (size_t)c->props.lc_buffer_size * sizeof(MqLCCell);
@@ -1016,7 +1018,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     memset(&F, 0, sizeof F);
     F.u = *u; F.W = c->W; F.H = c->H; F.tiles_x = c->tiles_x; F.tiles_y = c->tiles_y;
     F.n_local_tiles = c->n_local_tiles; F.rank = (uint32_t)c->rank; F.world = (uint32_t)c->world;
-    F.irradiance = (float*)c->d_out[MQ_OUT_IRRADIANCE].p; F.tiles_out = (float*)c->d_out[MQ_OUT_TILES].p; F.volume_tiles_out = (float*)c->d_out[MQ_OUT_VOLUME_TILES].p;
+    F.irradiance = (float*)c->d_out[MQ_OUT_IRRADIANCE].p; F.tiles_out = (float*)c->d_out[MQ_OUT_TILES].p; F.volume_tiles_out = (float*)c->d_out[MQ_OUT_VOLUME_TILES].p; F.vdepth_tiles_out = (uint16_t*)c->d_out[MQ_OUT_VOLUME_DEPTH_TILES].p;
     F.debug = (uint16_t*)c->d_out[MQ_OUT_DEBUG].p; F.debug_rng = (uint32_t*)c->d_debug_rng.p;
     F.gb_albedo = (uint16_t*)c->d_out[MQ_OUT_GB_ALBEDO].p; F.gb_irr = (uint16_t*)c->d_out[MQ_OUT_GB_IRRADIANCE].p;
     F.gb_mv = (uint16_t*)c->d_out[MQ_OUT_GB_MV].p; F.gbuffer = (uint32_t*)c->d_out[MQ_OUT_GBUFFER].p; F.hits = (uint32_t*)c->d_out[MQ_OUT_HITS].p;
@@ -1251,7 +1253,10 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         HIPCHK(c, hipMemcpyAsync(c->d_prev_vdepth.p, c->d_out[MQ_OUT_VOLUME_DEPTH].p, px * 2, hipMemcpyDeviceToDevice, s)); // delay-1 feedback connector
         HIPCHK(c, hipMemcpyAsync(c->d_out[MQ_OUT_VOLUME_MV].p, c->d_out[MQ_OUT_GB_MV].p, px * 4, hipMemcpyDeviceToDevice, s)); // :284-288
         if (c->params.volume_forward_project && !first_iteration) { // :296-311
-            e = mq_launch_forward_project(c->params, F, c->grid_blocks, s);
+            // every pixel of the image projects (a rank of a partitioned frame too: the caller gathers the ranks' volume_depth tiles,
+            // mq_untile_volume_depth; without that exchange the depths of the other ranks' pixels are stale zeros and project nothing)
+            MqFrame FA = F; FA.tile_mul = 1u; FA.tile_add = 0u; FA.n_local_tiles = c->tiles_x * c->tiles_y;
+            e = mq_launch_forward_project(c->params, FA, c->grid_blocks, s);
             if (e) return fail(c, MQ_EHIP, std::string("forward project launch: ") + hipGetErrorString((hipError_t)e));
         }
         for (int vs = 0; vs < c->params.volume_spp; vs++) {
@@ -1660,6 +1665,15 @@ int mq_untile_to(mq_ctx* c, const void* gathered_dev, void* image_dev, void* str
     if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
     HIPCHK(c, hipSetDevice(c->device));
     int e = mq_launch_untile(gathered_dev, image_dev, c->W, c->H, c->tiles_x, c->tiles_x * c->tiles_y, (uint32_t)c->world, c->tiles_per_rank, (hipStream_t)stream);
+    if (e) return fail(c, MQ_EHIP, std::string("untile launch: ") + hipGetErrorString((hipError_t)e));
+    return MQ_OK;
+}
+int mq_untile_volume_depth(mq_ctx* c, const void* gathered_dev, void* stream) {
+    if (!c || !gathered_dev) return MQ_EINVAL;
+    if (c->device < 0) return fail(c, MQ_ENODEVICE, "host-only context");
+    if (!c->connected) return fail(c, MQ_ESTATE, "not connected");
+    HIPCHK(c, hipSetDevice(c->device));
+    int e = mq_launch_untile16(gathered_dev, c->d_out[MQ_OUT_VOLUME_DEPTH].p, c->W, c->H, c->tiles_x, c->tiles_x * c->tiles_y, (uint32_t)c->world, c->tiles_per_rank, (hipStream_t)stream);
     if (e) return fail(c, MQ_EHIP, std::string("untile launch: ") + hipGetErrorString((hipError_t)e));
     return MQ_OK;
 }

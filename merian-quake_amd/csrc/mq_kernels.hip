@@ -1956,6 +1956,7 @@ __global__ void mq_volume_finish_kernel(MqParams P, MqFrame F) { // volume.comp:
         const float4 o4 = make_float4(__uint_as_float(a.x) * inv, __uint_as_float(a.y) * inv, __uint_as_float(a.z) * inv, __uint_as_float(a.w) * inv);
         *(float4*)(F.volume + 4 * ((size_t)py * F.W + px)) = o4;
         *(float4*)(F.volume_tiles_out + 4 * (size_t)my) = o4;
+        F.vdepth_tiles_out[my] = F.volume_depth[(size_t)py * F.W + px]; // (a pixel without a finite sample keeps its old depth: the tile copy mirrors the image)
     }
 }
 
@@ -2177,6 +2178,17 @@ __global__ void mq_untile_kernel(const float4* gathered, float4* image, uint32_t
     }
 }
 
+// the same for a 16-bit image (volume_depth)
+__global__ void mq_untile16_kernel(const uint16_t* gathered, uint16_t* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank) {
+    size_t n = (size_t)n_tiles * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t gtile = (uint32_t)(i >> 6), within = (uint32_t)(i & 63);
+        uint32_t r = gtile % world, lt = gtile / world;
+        uint32_t x = (gtile % tiles_x) * 8 + (within & 7), y = (gtile / tiles_x) * 8 + (within >> 3);
+        if (x < W && y < H) image[(size_t)y * W + x] = gathered[((size_t)r * tiles_per_rank + lt) * 64 + within];
+    }
+}
+
 __global__ __launch_bounds__(MQ_BLOCK) void mq_trace_kernel(MqSceneDev sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t_out, float* uv, unsigned long long* spill_base) {
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
     uint32_t gid = blockIdx.x * MQ_BLOCK + threadIdx.x;
@@ -2274,6 +2286,10 @@ int mq_launch_clear(const MqFrame& F, hipStream_t s) {
 }
 int mq_launch_untile(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s) {
     mq_untile_kernel<<<1024, 256, 0, s>>>((const float4*)gathered, (float4*)image, W, H, tiles_x, n_tiles, world, tiles_per_rank);
+    return (int)hipGetLastError();
+}
+int mq_launch_untile16(const void* gathered, void* image, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t tiles_per_rank, hipStream_t s) {
+    mq_untile16_kernel<<<1024, 256, 0, s>>>((const uint16_t*)gathered, (uint16_t*)image, W, H, tiles_x, n_tiles, world, tiles_per_rank);
     return (int)hipGetLastError();
 }
 int mq_launch_trace(const MqSceneDev& sc, const float* org, const float* dir, uint32_t n, uint32_t* prim, float* t, float* uv, unsigned long long* spill, int grid, hipStream_t s) {

@@ -225,6 +225,7 @@ struct MqFrame {
     float* irradiance;     // W*H*4 (full image, linear index) -- written for local tiles only
     float* tiles_out;      // n_local_tiles*64*4
     float* volume_tiles_out; // n_local_tiles*64*4: tile-major copy of `volume`
+    uint16_t* vdepth_tiles_out; // n_local_tiles*64: tile-major copy of `volume_depth` (the forward projection of the next frame reads every pixel's)
     uint16_t* debug;       // W*H*4 half: "debug" image (mcpg.comp:212-277), when connected
     uint32_t* debug_rng;   // W*H: the pixel's RNG state after its samples, kept for the debug view
     uint16_t* gb_albedo;   // W*H*4 half

@@ -20,7 +20,7 @@ MQ_GEO_OPAQUE, MQ_GEO_STATIC = 1, 2
 MQ_TEX_SRGB, MQ_TEX_LINEAR = 1, 2
 (OUT_IRRADIANCE, OUT_GB_ALBEDO, OUT_GB_IRRADIANCE, OUT_GB_MV, OUT_GBUFFER, OUT_HITS, OUT_TILES, OUT_VOLUME, OUT_VOLUME_DEPTH,
  OUT_VOLUME_MV, OUT_VOLUME_TILES, OUT_DEBUG, OUT_ACCUM, OUT_ACCUM_HISTORY, OUT_VOLUME_ACCUM, OUT_VOLUME_ACCUM_HISTORY, OUT_FINAL,
- OUT_RESTIR_IRRADIANCE, OUT_RESTIR_MOMENTS, OUT_RESTIR_RESERVOIRS, OUT_COUNT) = range(21)
+ OUT_RESTIR_IRRADIANCE, OUT_RESTIR_MOMENTS, OUT_RESTIR_RESERVOIRS, OUT_VOLUME_DEPTH_TILES, OUT_COUNT) = range(22)
 MQ_ENODEVICE = -2
 HALO_RESTIR_RESERVOIRS, HALO_ACCUM, HALO_ACCUM_HISTORY, HALO_VOLUME_ACCUM, HALO_VOLUME_ACCUM_HISTORY, HALO_COUNT = range(6)
 
@@ -177,6 +177,7 @@ def load_library(path=None):
         "mq_tiles_per_rank": (i32, [P, u32p, C.POINTER(sz)]),
         "mq_untile": (i32, [P, vp, vp]),
         "mq_untile_volume": (i32, [P, vp, vp]),
+        "mq_untile_volume_depth": (i32, [P, vp, vp]),
         "mq_untile_to": (i32, [P, vp, vp, vp]),
         "mq_band_layout": (i32, [P, u32, u32, i32, i32, C.POINTER(Band)]),
         "mq_band_gbuffer": (i32, [P, C.POINTER(Uniform), vp]),
@@ -531,6 +532,9 @@ class Context:
 
     def untile_volume(self, gathered_dev_ptr, stream=None):
         self._chk(self.lib.mq_untile_volume(self.h, gathered_dev_ptr, stream))
+
+    def untile_volume_depth(self, gathered_dev_ptr, stream=None):
+        self._chk(self.lib.mq_untile_volume_depth(self.h, gathered_dev_ptr, stream))
 
     def trace_rays(self, org, direction):
         org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)

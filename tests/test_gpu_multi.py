@@ -237,3 +237,67 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(mqlib, mode):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["backend"] == "gloo" and line["value"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
     assert ("overlapped" in line["config"]["collective"]) == (mode == "2")
+
+
+def test_partitioned_frame_forward_projects_from_every_pixel(mqlib):
+    """Config 4 on N ranks with the JSON default `"volume forward project": true`: the projection is a scatter from EVERY pixel of
+    last frame's `volume_depth` (render_mcpg.cpp:296-311), and a rank renders only its tiles.  With the third exchange buffer
+    (MQ_OUT_VOLUME_DEPTH_TILES, gathered and scattered back by mq_untile_volume_depth) every rank projects from the whole image:
+    guided volume frames from a given state -- their distance lookups follow `volume_mv` -- are bit-identical to the one-rank
+    frames in the `volume` tiles and in `volume_mv` at the rank's pixels."""
+    import torch
+    import mqhip
+    sys.path.insert(0, os.path.join(ROOT, "merian-quake_amd"))
+    import mq_tiles
+    W, H, world = 200, 120, 3
+    props = {"reference mode": 0, "randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3, "volume spp": 2, "particle size": 7.0, "volume: use LC": 1,
+             "dist guide p": 0.9, "Phase Prob": 0.1, "volume forward project": 1, "adaptive grid buf size": 1 << 16, "static grid buf size": 1 << 12, "LC buf size": 1 << 14}
+
+    def make(rank, nranks):
+        c = mqhip.Context(0)
+        c.header_defaults()
+        c.synth_scene("synth_start_fog", 3)
+        for k, v in props.items():
+            c.set_property(k, v)
+        c.commit(); c.set_partition(rank, nranks); c.connect(W, H)
+        return c
+    teacher = make(0, 1)
+    for f in range(8):
+        teacher.process(teacher.synth_camera(f))
+    n_mc, n_lc = props["adaptive grid buf size"] + props["static grid buf size"], props["LC buf size"]
+    state = (teacher.state_read(0, n_mc), teacher.state_read(1, n_lc), teacher.state_read(2, (W // 25 + 2) * (H // 25 + 2) * 10))  # render_mcpg.cpp:80-82
+    assert (state[2]["N"] > 0).sum() > 50
+    teacher.close()
+    single, ranks = make(0, 1), [make(r, world) for r in range(world)]
+    def exchange_depth():
+        depth = torch.cat([torch.from_numpy(c.read_output(mqhip.OUT_VOLUME_DEPTH_TILES).view(np.float32).copy()) for c in ranks]).cuda()
+        for c in ranks:
+            c.untile_volume_depth(depth.data_ptr())
+        torch.cuda.synchronize()
+    for c in [single] + ranks:
+        c.set_property("debug: freeze learning", 1)  # (from the first frame on: a free-running frame's distance chains depend on the order its pixels ran in)
+        c.process(c.synth_camera(8))  # the first frame zeroes the tables
+        for which, st in enumerate(state):
+            c.state_write(which, st)
+    exchange_depth()
+    moved = 0
+    for f in (10, 12, 14, 16):
+        u = single.synth_camera(f)
+        single.process(u)
+        for c in ranks:
+            c.process(u)
+        exchange_depth()
+        full, full_mv = single.volume(), single.read_output(mqhip.OUT_VOLUME_MV).view(np.uint32).reshape(H, W)
+        assert np.array_equal(ranks[0].read_output(mqhip.OUT_VOLUME_DEPTH), single.read_output(mqhip.OUT_VOLUME_DEPTH)), f
+        for r, c in enumerate(ranks):
+            got = c.read_output(mqhip.OUT_VOLUME_TILES).view(np.float32).reshape(-1, 64, 4)
+            want = mq_tiles.tile_image(full, r, world)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "frame %d rank %d: volume tiles differ in %d pixels" % (f, r, (got != want).any(-1).sum())
+            mv = c.read_output(mqhip.OUT_VOLUME_MV).view(np.uint32).reshape(H, W)
+            mine = mq_tiles.tile_image(np.repeat(mv[..., None], 4, -1), r, world)[..., 0], mq_tiles.tile_image(np.repeat(full_mv[..., None], 4, -1), r, world)[..., 0]
+            assert np.array_equal(mine[0], mine[1]), (f, r)
+        moved += int((full_mv != single.read_output(mqhip.OUT_GB_MV).view(np.uint32).reshape(H, W)).sum())
+        assert full[..., :3].sum() > 0
+    assert moved > 500, moved  # the projection rewrote vectors
+    for c in [single] + ranks:
+        c.close()
