@@ -50,7 +50,9 @@ def _frame_on_ranks(ranks, u, torch, mqhip):
 OUTS = ("OUT_RESTIR_RESERVOIRS", "OUT_RESTIR_IRRADIANCE", "OUT_RESTIR_MOMENTS", "OUT_ACCUM", "OUT_ACCUM_HISTORY", "OUT_FINAL", "OUT_GBUFFER", "OUT_HITS")
 
 
-@pytest.mark.parametrize("world,W,H,scene", [(2, 200, 120, "synth_start"), (3, 150, 90, "synth_materials"), (4, 328, 200, "synth_start"), (8, 328, 200, "synth_start")])
+@pytest.mark.parametrize("world,W,H,scene", [(2, 200, 120, "synth_start"), (3, 150, 90, "synth_materials"), (4, 328, 200, "synth_start"), (8, 328, 200, "synth_start"),
+                                             (5, 70, 44, "synth_tiny"),    # 6 rows of tiles on 5 ranks: bands thinner than the spatial radius, halos that span several ranks, a ragged last tile row
+                                             (8, 64, 40, "synth_tiny")])   # more ranks than rows of tiles: three ranks own nothing
 def test_restir_and_post_chain_on_row_bands_equal_the_single_rank_nodes(mqlib, world, W, H, scene):
     import torch
     import mqhip
@@ -80,7 +82,7 @@ def test_restir_and_post_chain_on_row_bands_equal_the_single_rank_nodes(mqlib, w
     assert merged > 2 * PROPS["restir: spp"], merged  # temporal + spatial reuse really merged reservoirs
     fin = single.image(mqhip.OUT_FINAL)
     assert np.isfinite(fin).all() and fin[..., :3].sum() > 0
-    assert single.read_output(mqhip.OUT_ACCUM_HISTORY).view(np.float32).max() >= 4  # histories survived the moving camera somewhere
+    assert single.read_output(mqhip.OUT_ACCUM_HISTORY).view(np.float32).max() >= (4 if H >= 90 else 2)  # histories survived the moving camera somewhere
     for c in ranks + [single]:
         assert c.counters()["queue_overflow"] == 0
         c.close()
