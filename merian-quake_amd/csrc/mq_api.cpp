@@ -145,6 +145,7 @@ struct mq_ctx {
     // ev_shaded[p]: the first-hit kernel that read buffer p has finished (the buffer may be overwritten).
     hipStream_t pt_stream = nullptr;
     DevBuf d_prim_hits[2];
+    DevBuf d_cam_spill[2];         // stack spill areas of the camera-ray kernel, per pixel slot: [0] the MCPG node's launches, [1] the row band's
     DevBuf d_band_hits;            // closest hits of the camera rays of a row band's g-buffer (ReSTIR node / post chain of a rank of a partitioned frame)
     uint32_t slot_tiles = 0;       // tiles the per-slot buffers (path records, hit buffers, ray queues) are sized for: the rank's share of interleaved tiles, or its widest row band
     bool band_gb_valid = false;    // the g-buffer of this rank's rows has been rendered for the frame mq_process last started
@@ -415,7 +416,7 @@ void free_frame_state(mq_ctx* c) {
     dev_free(c->d_restir_pong); dev_free(c->d_restir_prev); dev_free(c->d_restir_prev_gb);
     dev_free(c->d_post_prev_gb); for (int k = 0; k < 2; k++) { dev_free(c->d_post_prev_out[k]); dev_free(c->d_post_prev_hist[k]); }
     dev_free(c->d_prev_vdepth); dev_free(c->d_dist_mc); dev_free(c->d_fp_winner); dev_free(c->d_learn_log); dev_free(c->d_learn_count); c->learn_log_cap = 0; dev_free(c->d_lc_stats); dev_free(c->d_last_upd);
-    dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); dev_free(c->d_band_hits); c->shaded_valid[0] = c->shaded_valid[1] = false; c->bounced_valid = false;
+    dev_free(c->d_prim_hits[0]); dev_free(c->d_prim_hits[1]); dev_free(c->d_band_hits); dev_free(c->d_cam_spill[0]); dev_free(c->d_cam_spill[1]); c->shaded_valid[0] = c->shaded_valid[1] = false; c->bounced_valid = false;
     dev_free(c->d_debug_rng); dev_free(c->d_paths); dev_free(c->d_rays); dev_free(c->d_ray_hits); dev_free(c->d_qslots[0]); dev_free(c->d_qslots[1]);
     c->connected = false;
 }
@@ -936,15 +937,21 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_counters, sizeof(MqCountersDev)))) return r;
     HIPCHK(c, hipMemset(c->d_counters.p, 0, sizeof(MqCountersDev)));
     c->grid_blocks = std::max(1, c->cu_count) * 8;
-    // one region per sub-pipeline + one for the camera rays launched on pt_stream: those run BESIDE the previous frame's
-    // kernels (and the ReSTIR / volume passes) on the caller's stream, and a region is indexed by block and thread only
-    if ((r = dev_alloc(c, c->d_spill, (size_t)(c->subs + 1) * c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
+    // one region per sub-pipeline, indexed by block and thread of the (resident) grids.  The camera-ray launches have areas of their own,
+    // indexed by PIXEL SLOT (allocated below): they launch one wave per tile, and they run BESIDE the previous frame's kernels (and the
+    // ReSTIR / volume passes) on the caller's stream
+    if ((r = dev_alloc(c, c->d_spill, (size_t)c->subs * c->grid_blocks * mq_render_block_size() * mq_spill_entries() * 8))) return r;
     // per-slot buffers: the rank's share of interleaved tiles (MCPG node), or -- a rank of a partitioned frame also runs the ReSTIR
     // node and the g-buffer on a band of rows -- its widest band: rows owned + the largest spatial radius (100) + the reprojection halo
     c->slot_tiles = c->tiles_per_rank;
     if (c->world > 1) for (int rk = 0; rk < c->world; rk++) { const BandRows b = band_rows(c->props, h, rk, c->world, 100); c->slot_tiles = std::max(c->slot_tiles, (b.g1 - b.g0) * c->tiles_x); }
     const size_t slots = (size_t)c->slot_tiles * 64;
     if (c->world > 1 && (r = dev_alloc(c, c->d_band_hits, slots * 16))) return r;
+    // stack spill of the camera-ray kernel: 52 entries of 8 bytes per pixel slot (0.86 GB at 1920x1080, 3.5 GB at 3840x2160 of the 288 GB; touched
+    // only by rays whose stacks outgrow the 12 LDS entries); a second area for the row band's camera rays of a partitioned frame, which may
+    // run while the next frame's (overlapped) camera rays do
+    if ((r = dev_alloc(c, c->d_cam_spill[0], slots * (size_t)mq_spill_entries() * 8))) return r;
+    if (c->world > 1 && (r = dev_alloc(c, c->d_cam_spill[1], slots * (size_t)mq_spill_entries() * 8))) return r;
     c->band_gb_valid = false;
     if ((r = dev_alloc(c, c->d_paths, slots * 112))) return r; // 7 fields of 16 bytes (the volume pass uses 6)
     if ((r = dev_alloc(c, c->d_debug_rng, (size_t)c->W * c->H * 4))) return r;
@@ -1031,7 +1038,7 @@ static void fill_frame(mq_ctx* c, const mq_uniform* u, MqFrame& F, int sub = -1)
     F.paths = (uint4*)c->d_paths.p; F.n_slots = c->slot_tiles * 64u;
     F.tile_mul = (uint32_t)c->world; F.tile_add = (uint32_t)c->rank;
     F.rays = (float4*)c->d_rays.p + 4 * qoff; F.ray_hits = (uint4*)c->d_ray_hits.p + qoff; // rays: two buffers (round parity) of origins + directions per region
-    F.prim_hits = (uint4*)c->d_prim_hits[c->frame_parity & 1].p;
+    F.prim_hits = (uint4*)c->d_prim_hits[c->frame_parity & 1].p; F.cam_spill = (unsigned long long*)c->d_cam_spill[0].p;
     F.queue_slots[0] = (uint32_t*)c->d_qslots[0].p + qoff; F.queue_slots[1] = (uint32_t*)c->d_qslots[1].p + qoff;
     F.ray_cap = sub < 0 ? c->ray_cap : c->sub_ray_cap;
     { // test hook: tell the kernels of a smaller queue than the one allocated, so that the overflow path (rays dropped, frame flagged) runs
@@ -1204,9 +1211,15 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     const bool packet = c->props.packet_camera_rays && (int)std::max(c->s_depth, c->d_depth) + 2 <= mq_packet_stack_entries();
     if (!c->count_enabled) // camera rays: traversal in its own launch (the counting instantiation of the primary kernel traces them inline)
         for (int k = 0; k < S; k++) {
-            MqFrame FP = FS[k];
-            if (overlap_pt) FP.stack_spill = (unsigned long long*)c->d_spill.p + (size_t)S * c->grid_blocks * mq_render_block_size() * mq_spill_entries(); // pt_stream's own region (its launches run one after the other)
-            e = mq_launch_primary_trace(c->scene, c->params, FP, packet, overlap_pt ? c->grid_frame[3] : sub_grid(3), overlap_pt ? c->pt_stream : st(k));
+            MqFrame FP = FS[k]; // (its stack spill area: MqFrame::cam_spill, one per pixel slot)
+            // Camera rays: ONE WAVE PER TILE, every block launched (round 3).  The other frame kernels run resident grids with grid-stride
+            // loops; here the hardware's block dispatch is the better scheduler -- tiles differ in cost (sky against interiors), a wave
+            // that has finished its tile makes room at once, and blocks that come and go let the frame's own (higher-priority) launches
+            // in: 0.45 -> 0.39 ms for the overlapped launch, 1.87 -> 1.80 ms per frame (profiles/r03_y_camera_ray_grid.txt).  The
+            // packet kernel keeps its resident grid (one tile per wave per trip).
+            static const bool cam_resident = getenv("MQ_DEBUG_CAMERA_GRID_RESIDENT") != nullptr; // the A/B switch
+            const int cam_grid = (packet || cam_resident) ? (overlap_pt ? c->grid_frame[3] : sub_grid(3)) : (int)((FP.slot_end - FP.slot_begin + 255u) / 256u);
+            e = mq_launch_primary_trace(c->scene, c->params, FP, packet, std::max(1, cam_grid), overlap_pt ? c->pt_stream : st(k));
             if (e) return fail(c, MQ_EHIP, std::string("primary trace launch: ") + hipGetErrorString((hipError_t)e));
         }
     if (overlap_pt) {
@@ -1217,7 +1230,11 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     }
     if (detail) HIPCHK(c, hipEventRecord(ev[1], s));
     for (int k = 0; k < S; k++) {
-        e = mq_launch_primary(c->scene, c->params, FS[k], guided, c->count_enabled, sub_grid(0), st(k));
+        // first-hit shading: one thread per pixel slot, every block launched (0.315 -> 0.304 ms against the resident grid; same A/B).  The
+        // counting instantiation traces inline and indexes its stack spill area by block: resident grid.
+        static const bool prim_resident = getenv("MQ_DEBUG_PRIMARY_GRID_RESIDENT") != nullptr;
+        const int prim_grid = (c->count_enabled || prim_resident) ? sub_grid(0) : std::max(1, (int)((FS[k].slot_end - FS[k].slot_begin + FS[k].shade_block - 1) / FS[k].shade_block));
+        e = mq_launch_primary(c->scene, c->params, FS[k], guided, c->count_enabled, prim_grid, st(k));
         if (e) return fail(c, MQ_EHIP, std::string("primary launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (rounds == 0) { int r = join(); if (r) return r; }
@@ -1435,10 +1452,10 @@ static int ensure_band_gbuffer(mq_ctx* c, const mq_uniform* u, hipStream_t s) {
     if (F.n_local_tiles > c->slot_tiles) return fail(c, MQ_ESTATE, "row band larger than the buffers of this connect (reconnect after changing the partition)");
     F.slot_begin = 0u; F.slot_end = F.n_local_tiles * 64u;
     F.gbuffer_only = 1u;
-    F.prim_hits = (uint4*)c->d_band_hits.p;
+    F.prim_hits = (uint4*)c->d_band_hits.p; F.cam_spill = (unsigned long long*)c->d_cam_spill[1].p;
     if (F.n_local_tiles) {
-        int e = mq_launch_primary_trace(c->scene, c->params, F, false, c->grid_frame[3], s);
-        if (!e) e = mq_launch_primary(c->scene, c->params, F, false, false, c->grid_frame[0], s);
+        int e = mq_launch_primary_trace(c->scene, c->params, F, false, (int)((F.slot_end + 255u) / 256u), s);
+        if (!e) e = mq_launch_primary(c->scene, c->params, F, false, false, (int)((F.slot_end + F.shade_block - 1) / F.shade_block), s);
         if (e) return fail(c, MQ_EHIP, std::string("band g-buffer launch: ") + hipGetErrorString((hipError_t)e));
     }
     c->band_gb_valid = true;

@@ -1225,12 +1225,12 @@ __global__ __launch_bounds__(MQ_BLOCK, MQ_OCC_TRACE) void mq_primary_trace_lanes
     __shared__ uint2 s_stack[MQ_WAVES][MQ_STACK_LDS][64];
     const int lane = threadIdx.x & 63;
     uint2* stk = &s_stack[threadIdx.x >> 6][0][lane];
-    unsigned long long* spill = F.stack_spill + (size_t)(blockIdx.x * MQ_BLOCK + threadIdx.x) * MQ_SPILL_ENTRIES;
     const mq_uniform& U = F.u;
     const uint32_t total = F.slot_end; // this pipeline's pixel slots: [slot_begin, slot_end)
     const float Wf = (float)F.W, Hf = (float)F.H;
     Ctr ctr = {};
-    for (uint32_t my = F.slot_begin + blockIdx.x * MQ_BLOCK + threadIdx.x; my < total; my += gridDim.x * MQ_BLOCK) {
+    for (uint32_t my = F.slot_begin + blockIdx.x * MQ_BLOCK + threadIdx.x; my < total; my += gridDim.x * MQ_BLOCK) { // (the host launches one wave per tile: one trip)
+        unsigned long long* spill = F.cam_spill + (size_t)my * MQ_SPILL_ENTRIES; // per pixel slot: whatever else runs beside this launch has its own area
         const uint32_t gtile = MQ_GTILE(F, my >> 6), within = my & 63u;
         const uint32_t px = (gtile % F.tiles_x) * 8u + (within & 7u), py = (gtile / F.tiles_x) * 8u + (within >> 3);
         if (px >= F.W || py >= F.H) continue;

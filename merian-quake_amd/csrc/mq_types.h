@@ -268,6 +268,7 @@ struct MqFrame {
     uint32_t count_stats;  // != 0: kernels without a COUNT instantiation may bump `counters` too
     // traversal stack spill area: MQ_SPILL_ENTRIES 8-byte entries per resident lane
     unsigned long long* stack_spill;
+    unsigned long long* cam_spill; // the camera-ray kernel's: MQ_SPILL_ENTRIES entries per PIXEL SLOT (it launches one wave per tile, and beside other kernels)
     // statistics of the reference's dumps (render_mcpg.cpp:354-416), kept only while "debug: LC lock statistics" is set:
     uint2* lc_stats;          // per light-cache cell: update_succeeded, update_canceled (grid.h:44-45)
     uint32_t* last_upd_count; // per Markov-chain slot: last_update_count (grid.h:25, compute_updates.comp:121)
