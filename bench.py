@@ -76,19 +76,41 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+def host_cores():
+    """Cores this process may really use: its affinity mask, cut to the container's CPU quota (a GPU box shows 256 hardware threads
+    to a job that is given 16 cores' worth of time: 256 worker threads would only take turns)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if period_file is None:
+                q, p = open(quota_file).read().split()[:2]
+            else:
+                q, p = open(quota_file).read().strip(), open(period_file).read().strip()
+            if q != "max" and float(q) > 0:
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, min(256, n))
+
+
 def cpu_baseline(ctx, scene, seed, props, W, H, warm, timed):
     """Naive CPU path tracer (the oracle: plain binary BVH, scalar code) on a bounded sample: a persistent pool of one worker
     thread per host core the process may run on, rows claimed dynamically, the update pass spread over the workers too."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    cores = min(256, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = host_cores()
     p = orc.params_from_ctx(ctx, ctx.get_constants())
     o = orc.Oracle(p)
     orc.mirror_scene(ctx, o)
     o.commit(1)
     o.connect(W, H)
     for f in range(warm):
+        w0, p0 = time.perf_counter(), time.process_time()
         o.process(ctx.synth_camera(f), threads=cores, parallel_update=True)
+        got = (time.process_time() - p0) / max(1e-9, time.perf_counter() - w0)
+        if f == 0 and got < 0.75 * cores:  # a CPU quota no file told us about: as many workers as the job really gets to run at once
+            cores = max(1, int(got + 0.5))
     t0 = time.perf_counter()
     c0 = time.process_time()
     for f in range(warm, warm + timed):
