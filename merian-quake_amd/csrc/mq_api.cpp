@@ -976,6 +976,11 @@ int mq_connect(mq_ctx* c, uint32_t w, uint32_t h) {
     if ((r = dev_alloc(c, c->d_restir_pong, (size_t)w * h * 64))) return r;
     if ((r = dev_alloc(c, c->d_restir_prev, (size_t)w * h * 64))) return r;
     if ((r = dev_alloc(c, c->d_restir_prev_gb, (size_t)w * h * 16))) return r;
+    // the delay-1 buffers start as zeros: a rank of a row partition whose caller has not (yet) delivered the other ranks' halo rows then
+    // reads empty reservoirs / a zero history there -- "no history", never uninitialised memory
+    HIPCHK(c, hipMemset(c->d_restir_prev.p, 0, c->d_restir_prev.bytes)); HIPCHK(c, hipMemset(c->d_restir_prev_gb.p, 0, c->d_restir_prev_gb.bytes));
+    HIPCHK(c, hipMemset(c->d_post_prev_gb.p, 0, c->d_post_prev_gb.bytes));
+    for (int k = 0; k < 2; k++) { HIPCHK(c, hipMemset(c->d_post_prev_out[k].p, 0, c->d_post_prev_out[k].bytes)); HIPCHK(c, hipMemset(c->d_post_prev_hist[k].p, 0, c->d_post_prev_hist[k].bytes)); }
     c->restir_iteration = 0; c->restir_seeded = false;
     c->dist_mc_n = (uint32_t)(d.state_bytes_volume_distancemc / sizeof(MqDistMC));
     if ((r = dev_alloc(c, c->d_dist_mc, d.state_bytes_volume_distancemc))) return r;
