@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "mq_host.h"
 #include "mq_device.h" // host-callable grid_width(): the per-level tables must carry the kernels' own float results
 
@@ -55,6 +57,29 @@ int mq_spill_entries();
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
+};
+
+// Named ranges for rocprofv3 --marker-trace, with the reference's own scope names (MERIAN_PROFILE_SCOPE_GPU "surface", "volume", "volume forward
+// project", "copy mv for volume", "clear": render_mcpg.cpp:244,255,283,300,315; the ReSTIR node's "generate samples", "temporal reuse", "spatial
+// reuse", "shade": renderer_restir.cpp:189-250).  roctx is looked up at run time (a profiler preloads it; MQ_ROCTX=1 loads it by hand): the
+// library has no link-time dependency on it, and without it a range is two null-pointer tests.
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx() {
+        void* h = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!h && getenv("MQ_ROCTX")) for (const char* n : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) if ((h = dlopen(n, RTLD_NOW))) break;
+        if (h) { push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop"); }
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+struct RoctxRange {
+    static const Roctx& api() { static const Roctx r; return r; }
+    bool on;
+    explicit RoctxRange(const char* name) : on(api().push != nullptr) { if (on) api().push(name); }
+    void end() { if (on) { api().pop(); on = false; } }
+    ~RoctxRange() { end(); }
+    RoctxRange(const RoctxRange&) = delete; RoctxRange& operator=(const RoctxRange&) = delete;
 };
 
 struct mq_ctx {
@@ -1145,6 +1170,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     c->iteration++;
     c->band_gb_valid = false; // a new frame: the ReSTIR node / post chain of a partitioned frame render the g-buffer of their rows again
     if (!render) { // render_mcpg.cpp:243-250
+        RoctxRange rr("clear");
         int e = mq_launch_clear(F, s);
         if (e) return fail(c, MQ_EHIP, std::string("clear launch: ") + hipGetErrorString((hipError_t)e));
         return MQ_OK;
@@ -1166,6 +1192,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     c->ev_detail[slot] = detail;
     HIPCHK(c, hipEventRecord(ev[0], s));
     int e = 0;
+    RoctxRange rr_surface("surface"); // render_mcpg.cpp:255
     // ---- surface pass: `subs` independent chains of launches (each over its own pixel slots, with its own queues) on
     // `subs` streams.  A launch of this pipeline ends with the tail of its longest ray or path on a nearly idle chip;
     // with several chains in flight the tail of one overlaps the body of another.  Chain 0 runs on the caller's stream
@@ -1260,17 +1287,20 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
         if (overlap_pt && 2 * r + 1 == 2 * rounds - 1 - pt_behind) { HIPCHK(c, hipEventRecord(c->ev_bounced, s)); c->bounced_valid = true; }
         if (r < timed && (detail || r == timed - 1)) HIPCHK(c, hipEventRecord(ev[4 + 2 * r], s)); // the last one ends the render interval
     }
+    rr_surface.end();
     if (c->params.debug_output_connected) { // mcpg.comp:212-277: part of the surface pass, i.e. before the update pass
         e = mq_launch_debug_view(c->params, F, c->grid_blocks, s);
         if (e) return fail(c, MQ_EHIP, std::string("debug view launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (guided) { // render_mcpg.cpp:261-277
+        RoctxRange rr("update");
         e = mq_launch_apply(c->params, F, std::max(1, c->cu_count) * 8, c->props.sequential_update_pass ? c->mc_total : 0u, s);
         if (e) return fail(c, MQ_EHIP, std::string("apply launch: ") + hipGetErrorString((hipError_t)e));
     }
     // ---- volume passes, render_mcpg.cpp:280-320 (their device time is part of the update interval) ----
     if (guided) c->queues_dirty = volume; // the update pass zeroed the control words of every queue (reset_queue_control): volume entries start at 0
     if (volume) {
+        RoctxRange rr("volume");
         const size_t px = (size_t)c->W * c->H;
         HIPCHK(c, hipMemcpyAsync(c->d_prev_vdepth.p, c->d_out[MQ_OUT_VOLUME_DEPTH].p, px * 2, hipMemcpyDeviceToDevice, s)); // delay-1 feedback connector
         HIPCHK(c, hipMemcpyAsync(c->d_out[MQ_OUT_VOLUME_MV].p, c->d_out[MQ_OUT_GB_MV].p, px * 4, hipMemcpyDeviceToDevice, s)); // :284-288
@@ -1518,6 +1548,7 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
     if (!render) { // renderer_restir.cpp:189-197: the clear pass writes set (1): `reservoirs` = the graph output
         F.res_a = out; F.res_read = pong;
         rows(own);
+        RoctxRange rr("clear");
         e = mq_launch_restir(c->scene, c->params, R, F, 4, grid, s);
         if (e) return fail(c, MQ_EHIP, std::string("restir clear launch: ") + hipGetErrorString((hipError_t)e));
     } else {
@@ -1541,13 +1572,14 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
             return e2;
         };
         rows(wide);
-        if (wavefront) { for (int smp = 0; smp < std::max(1, R.spp) && !e; smp++) e = traced_pass(0, smp); }
-        else e = mq_launch_restir(c->scene, c->params, R, F, 0, grid, s);
-        if (!e && q.restir_temporal_reuse && c->restir_iteration > 0) e = mq_launch_restir(c->scene, c->params, R, F, 1, grid_of(1), s);
+        { RoctxRange rr("generate samples");
+          if (wavefront) { for (int smp = 0; smp < std::max(1, R.spp) && !e; smp++) e = traced_pass(0, smp); }
+          else e = mq_launch_restir(c->scene, c->params, R, F, 0, grid, s); }
+        if (!e && q.restir_temporal_reuse && c->restir_iteration > 0) { RoctxRange rr("temporal reuse"); e = mq_launch_restir(c->scene, c->params, R, F, 1, grid_of(1), s); }
         rows(own);
-        if (!e && spatial) { F.res_a = out; F.res_read = pong; e = mq_launch_restir(c->scene, c->params, R, F, 2, grid_of(2), s); }
+        if (!e && spatial) { RoctxRange rr("spatial reuse"); F.res_a = out; F.res_read = pong; e = mq_launch_restir(c->scene, c->params, R, F, 2, grid_of(2), s); }
         F.res_a = out; F.res_read = pong;
-        if (!e) e = wavefront ? traced_pass(2, std::max(1, R.spp)) : mq_launch_restir(c->scene, c->params, R, F, 3, grid_of(3), s);
+        if (!e) { RoctxRange rr("shade"); e = wavefront ? traced_pass(2, std::max(1, R.spp)) : mq_launch_restir(c->scene, c->params, R, F, 3, grid_of(3), s); }
         if (e) return fail(c, MQ_EHIP, std::string("restir launch: ") + hipGetErrorString((hipError_t)e));
     }
     // the graph's delay-1 inputs of the next frame: "reservoirs" (the rows this rank owns; the others arrive from their owners,
@@ -1579,6 +1611,7 @@ int mq_post_process(mq_ctx* c, void* stream) {
     const int src[2] = {MQ_OUT_IRRADIANCE, MQ_OUT_VOLUME}, mv[2] = {MQ_OUT_GB_MV, c->world > 1 ? MQ_OUT_GB_MV : MQ_OUT_VOLUME_MV}, out[2] = {MQ_OUT_ACCUM, MQ_OUT_VOLUME_ACCUM}, hist[2] = {MQ_OUT_ACCUM_HISTORY, MQ_OUT_VOLUME_ACCUM_HISTORY};
     const BandRows b = band_rows(q, c->H, c->rank, c->world);
     const uint32_t rows[4] = {b.t0 * 8u, std::min(c->H, b.t1 * 8u), b.g0 * 8u, std::min(c->H, b.g1 * 8u)};
+    RoctxRange rr_post("accumulate + add");
     for (int k = 0; k < 2; k++) {
         // volume accum.mv <- render_markovchain.volume_mv: only written by frames with a volume pass; without one there is no motion to follow
         const bool have_vmv = k == 0 || (c->params.volume_spp > 0 && !c->volume_outputs_zero);
