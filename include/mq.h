@@ -170,13 +170,20 @@ int mq_scene_set_texture(mq_ctx* ctx, uint32_t texnum, uint32_t w, uint32_t h,
  * frame) slots flagged MQ_GEO_STATIC form one tree that is rebuilt and uploaded only when one of them
  * (or a texture) changed; the other slots form a second tree, stored behind the first, that every
  * commit rebuilds -- a commit after changing only non-static slots rewrites just that part of the
- * device arrays.  Rays visit the second tree after the first.  The call waits for frames in flight. */
+ * device arrays.  Rays visit the second tree after the first.
+ * A commit of per-frame geometry does NOT wait for the frames in flight: the device arrays hold two regions for the
+ * per-frame part, the commit writes the one those frames do not read (asynchronously, from pinned staging memory, on a
+ * stream of its own) and waits only for the last launch that read it, two commits ago -- the host builds the tree of
+ * frame n + 1 while the device renders frame n.  A commit that changes static geometry or textures, the first commit,
+ * one whose per-frame part outgrows its region, and per-frame geometry without any static geometry wait for the device. */
 int mq_scene_commit(mq_ctx* ctx);
 /* nodes [0, static_nodes) / triangles [0, static_tris) of mq_scene_get_bvh are the static tree (root 0); the
  * per-frame tree follows (root = node static_nodes) */
 int mq_scene_layout(const mq_ctx* ctx, uint64_t* static_nodes, uint64_t* static_tris);
 /* how many commits took the full path and how many only rewrote the per-frame part */
 int mq_scene_commit_counts(const mq_ctx* ctx, uint32_t* full, uint32_t* per_frame);
+/* how many of the per-frame commits did not wait for the device (see mq_scene_commit) */
+int mq_scene_commit_async_count(const mq_ctx* ctx, uint32_t* n);
 /* QuakeRenderInfo::constant + constant_data_update, src/game/quake_node.hpp:62-84 */
 int mq_set_constants(mq_ctx* ctx, const mq_constants* c);
 int mq_get_constants(const mq_ctx* ctx, mq_constants* out);

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -113,6 +114,18 @@ struct mq_ctx {
     DevBuf d_nodes, d_tris, d_leaves, d_shade, d_texdesc, d_texels;
     DevBuf d_ext[MQ_MAX_GEOMETRIES], d_idx[MQ_MAX_GEOMETRIES], d_prev[MQ_MAX_GEOMETRIES];
     MqSceneDev scene{};
+    // Per-frame geometry is DOUBLE-BUFFERED on the device: behind the static part of nodes / tris / leaves / shading records lie two
+    // regions of dyn_cap_* entries, and a commit of per-frame geometry writes the one the frames in flight do not read (asynchronously,
+    // from pinned staging memory, on its own stream) -- the host builds frame n + 1's tree while the device renders frame n.
+    uint32_t dyn_cap_nodes = 0, dyn_cap_tris = 0; // entries per region (0: the device arrays hold no second region)
+    int dyn_parity = 0;                           // region the current scene (c->scene) points at
+    DevBuf d_ext_b[MQ_MAX_GEOMETRIES], d_idx_b[MQ_MAX_GEOMETRIES], d_prev_b[MQ_MAX_GEOMETRIES]; // the per-slot arrays of region 1 (region 0: d_ext / d_idx / d_prev)
+    void* stage[2] = {nullptr, nullptr}; size_t stage_bytes[2] = {0, 0}; // pinned staging memory per region
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_uploaded = nullptr; bool uploaded_valid = false;       // the last asynchronous commit has landed
+    hipEvent_t ev_scene_used[2] = {nullptr, nullptr}; bool scene_used_valid[2] = {false, false}; // last launch that read region p
+    hipStream_t scene_used_stream[2] = {nullptr, nullptr}; bool scene_used_mixed[2] = {false, false}; // (read from more than one stream: the commit falls back to a device synchronisation)
+    uint32_t commits_async = 0;
     // frame state
     bool connected = false;
     uint32_t W = 0, H = 0, tiles_x = 0, tiles_y = 0;
@@ -447,7 +460,8 @@ void free_frame_state(mq_ctx* c) {
 }
 void free_scene_dev(mq_ctx* c) {
     dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_leaves); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels);
-    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); }
+    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); dev_free(c->d_ext_b[s]); dev_free(c->d_idx_b[s]); dev_free(c->d_prev_b[s]); }
+    c->dyn_cap_nodes = c->dyn_cap_tris = 0; c->dyn_parity = 0;
 }
 
 // Update-queue capacity: one entry per traced segment of the frame (every segment can queue at most one update) plus
@@ -557,6 +571,9 @@ void mq_destroy(mq_ctx* c) {
         if (c->pt_stream) (void)hipStreamDestroy(c->pt_stream);
         for (int k = 0; k < 2; k++) { if (c->ev_pt_done[k]) (void)hipEventDestroy(c->ev_pt_done[k]); if (c->ev_shaded[k]) (void)hipEventDestroy(c->ev_shaded[k]); }
         if (c->ev_bounced) (void)hipEventDestroy(c->ev_bounced);
+        if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+        if (c->ev_uploaded) (void)hipEventDestroy(c->ev_uploaded);
+        for (int k = 0; k < 2; k++) { if (c->ev_scene_used[k]) (void)hipEventDestroy(c->ev_scene_used[k]); if (c->stage[k]) (void)hipHostFree(c->stage[k]); }
         for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) if (e4) (void)hipEventDestroy(e4);
         for (int k = 0; k < mq_ctx::MAX_SUBS - 1; k++) { if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); if (c->side[k]) (void)hipStreamDestroy(c->side[k]); }
     }
@@ -719,34 +736,44 @@ int mq_scene_stats(const mq_ctx* c, uint64_t* n_tris, uint64_t* n_nodes, uint64_
 
 namespace {
 void flatten_slots(mq_ctx* c, bool want_static, std::vector<MqTri>& flat) {
-    flat.clear();
+    size_t total = 0;
+    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) if (((c->geo[s].flags & MQ_GEO_STATIC) != 0) == want_static) total += c->geo[s].n_tri();
+    flat.resize(total);
+    size_t at = 0;
     for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) {
         MqHostGeo& g = c->geo[s];
         if (((g.flags & MQ_GEO_STATIC) != 0) != want_static) continue;
         g.dynamic = g.prev_vtx.size() == g.vtx.size() && !g.vtx.empty() && memcmp(g.prev_vtx.data(), g.vtx.data(), g.vtx.size() * 4) != 0;
-        for (uint32_t i = 0; i < g.n_tri(); i++) {
-            MqTri t; memset(&t, 0, sizeof t);
-            memcpy(t.v0, &g.vtx[3 * (size_t)g.idx[3 * i]], 12); memcpy(t.v1, &g.vtx[3 * (size_t)g.idx[3 * i + 1]], 12); memcpy(t.v2, &g.vtx[3 * (size_t)g.idx[3 * i + 2]], 12);
-            t.key = ((uint32_t)s << 28) | i;
-            t.flags = ((g.flags & MQ_GEO_OPAQUE) ? 0u : MQ_TRI_ANYHIT) | (g.dynamic ? MQ_TRI_DYNAMIC : 0u);
-            flat.push_back(t);
-        }
+        const uint32_t tflags = ((g.flags & MQ_GEO_OPAQUE) ? 0u : MQ_TRI_ANYHIT) | (g.dynamic ? MQ_TRI_DYNAMIC : 0u);
+        MqTri* out = flat.data() + at;
+        mq_parallel_for(g.n_tri(), 8192, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; i++) {
+                MqTri t; memset(&t, 0, sizeof t);
+                memcpy(t.v0, &g.vtx[3 * (size_t)g.idx[3 * i]], 12); memcpy(t.v1, &g.vtx[3 * (size_t)g.idx[3 * i + 1]], 12); memcpy(t.v2, &g.vtx[3 * (size_t)g.idx[3 * i + 2]], 12);
+                t.key = ((uint32_t)s << 28) | (uint32_t)i;
+                t.flags = tflags;
+                out[i] = t;
+            }
+        });
+        at += g.n_tri();
     }
 }
 
 void shade_records(const mq_ctx* c, const MqTri* tris, size_t n, std::vector<MqShadeRec>& recs) {
     recs.resize(n);
     const std::vector<MqTexDesc>& desc = c->texdesc;
-    for (size_t i = 0; i < n; i++) {
-        const uint32_t key = tris[i].key;
-        const mq_ext& e = c->geo[key >> 28].ext[key & 0x0fffffffu];
-        MqShadeRec& q = recs[i]; memset(&q, 0, sizeof q);
-        static_assert(sizeof(mq_ext) == 28, "extra data is 7 dwords");
-        memcpy(q.ext, &e, 28);
-        q.albedo = desc[std::min<uint32_t>(e.texnum_alpha & 0xfffu, MQ_MAX_GLTEXTURES - 1)];
-        const uint32_t fb = e.texnum_fb_flags & 0xfffu;
-        if (fb < MQ_MAX_GLTEXTURES) q.fb = desc[fb]; else { q.fb.offset = MQ_NIL; }
-    }
+    mq_parallel_for(n, 8192, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            const uint32_t key = tris[i].key;
+            const mq_ext& x = c->geo[key >> 28].ext[key & 0x0fffffffu];
+            MqShadeRec& q = recs[i]; memset(&q, 0, sizeof q);
+            static_assert(sizeof(mq_ext) == 28, "extra data is 7 dwords");
+            memcpy(q.ext, &x, 28);
+            q.albedo = desc[std::min<uint32_t>(x.texnum_alpha & 0xfffu, MQ_MAX_GLTEXTURES - 1)];
+            const uint32_t fb = x.texnum_fb_flags & 0xfffu;
+            if (fb < MQ_MAX_GLTEXTURES) q.fb = desc[fb]; else { q.fb.offset = MQ_NIL; }
+        }
+    });
 }
 
 // per-slot arrays the kernels read for triangles with distinct previous positions (raytrace.glsl:226-228)
@@ -767,10 +794,26 @@ int upload_slot_arrays(mq_ctx* c, bool statics) {
     }
     return MQ_OK;
 }
+
+// Launches that read the scene: scene_ready() first (the last asynchronous commit of per-frame geometry must have landed),
+// scene_used() behind the last of them (the next commit but one overwrites the region they read).
+int scene_ready(mq_ctx* c, hipStream_t s) {
+    if (c->uploaded_valid) HIPCHK(c, hipStreamWaitEvent(s, c->ev_uploaded, 0));
+    return MQ_OK;
+}
+int scene_used(mq_ctx* c, hipStream_t s) {
+    if (!c->up_stream) return MQ_OK; // no asynchronous commit so far: the first one synchronises with the device
+    const int p = c->dyn_parity;
+    if (c->scene_used_valid[p] && c->scene_used_stream[p] != s) c->scene_used_mixed[p] = true;
+    HIPCHK(c, hipEventRecord(c->ev_scene_used[p], s));
+    c->scene_used_valid[p] = true; c->scene_used_stream[p] = s;
+    return MQ_OK;
+}
 } // namespace
 
 int mq_scene_commit(mq_ctx* c) {
     if (!c) return MQ_EINVAL;
+    const auto t_commit = std::chrono::steady_clock::now();
     std::string err;
     std::vector<MqTri> flat;
     const bool static_rebuilt = c->static_dirty;
@@ -798,12 +841,97 @@ int mq_scene_commit(mq_ctx* c) {
     c->committed = true;
     if (c->device < 0) { c->tex_dirty = false; return MQ_OK; } // host-only context: BVH available for inspection, nothing to upload
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
     int r;
-    const bool partial = in_place && !c->tex_dirty && c->dev_scene_valid && c->dev_static_nodes == ns && c->dev_static_tris == ts && c->dev_static_leaves == ls
-        && c->d_nodes.bytes >= c->nodes.size() * sizeof(MqNode) && c->d_tris.bytes >= c->tris.size() * sizeof(MqTri) && c->d_shade.bytes >= c->tris.size() * sizeof(MqShadeRec)
-        && c->d_leaves.bytes >= c->leaves.size() * sizeof(MqLeafRec);
-    if (partial) { // per-frame geometry only: root pair, the per-frame tree, its triangles and shading records
+    const bool partial = in_place && !c->tex_dirty && c->dev_scene_valid && c->dev_static_nodes == ns && c->dev_static_tris == ts && c->dev_static_leaves == ls;
+    // Per-frame geometry only, the usual case of a running game (quake_node.cpp:896-983 rebuilds it every frame): the static part
+    // stays where it is, the per-frame tree, its triangles, leaf records, shading records and per-slot arrays go into the region of
+    // the device arrays that the frames in flight do NOT read, asynchronously.  Nothing here waits for the device except for the
+    // last launch that read that region, two commits ago.  (Without static geometry the per-frame tree starts at node 0 and there
+    // is only one place for it: the synchronous path below.)
+    static const bool force_sync = getenv("MQ_DEBUG_COMMIT_SYNC") != nullptr; // the A/B switch: wait for the device, write in place (round 2's commit)
+    const bool fits = c->dyn_cap_tris != 0 && nd <= c->dyn_cap_nodes && td <= c->dyn_cap_tris && ld <= c->dyn_cap_tris;
+    if (partial && ns != 0 && fits && !force_sync) {
+        const int p = c->dyn_parity ^ 1;
+        if (!c->up_stream) { // first asynchronous commit: whatever read the scene so far is unknown to the events below
+            HIPCHK(c, hipDeviceSynchronize());
+            HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_uploaded, hipEventDisableTiming));
+            for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_scene_used[k], hipEventDisableTiming));
+        }
+        static const bool times = getenv("MQ_DEBUG_COMMIT_TIMES") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_a = now();
+        if (c->scene_used_mixed[p]) { HIPCHK(c, hipDeviceSynchronize()); }
+        else if (c->scene_used_valid[p]) HIPCHK(c, hipEventSynchronize(c->ev_scene_used[p]));
+        c->scene_used_valid[p] = false; c->scene_used_mixed[p] = false;
+        const auto t_b = now();
+        HIPCHK(c, hipStreamSynchronize(c->up_stream)); // (the staging memory of region p was last read by the copies of two commits ago: long done)
+        const auto t_c = now();
+        const size_t on = ns + (size_t)p * c->dyn_cap_nodes, ot = ts + (size_t)p * c->dyn_cap_tris, ol = ls + (size_t)p * c->dyn_cap_tris; // where region p starts
+        // staging layout: nodes | tris | leaves | shading records | per-slot arrays, each 256-byte aligned
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        size_t need = al(nd * sizeof(MqNode)) + al(td * sizeof(MqTri)) + al(ld * sizeof(MqLeafRec)) + al(td * sizeof(MqShadeRec));
+        for (int sl = 0; sl < MQ_MAX_GEOMETRIES; sl++) {
+            const MqHostGeo& g = c->geo[sl];
+            if ((g.flags & MQ_GEO_STATIC) || !g.n_tri()) continue;
+            need += al(g.ext.size() * sizeof(mq_ext)) + al(g.idx.size() * 4) + al(g.prev_vtx.size() * 4);
+        }
+        if (c->stage_bytes[p] < need) {
+            if (c->stage[p]) HIPCHK(c, hipHostFree(c->stage[p]));
+            c->stage[p] = nullptr; c->stage_bytes[p] = 0;
+            HIPCHK(c, hipHostMalloc(&c->stage[p], need + need / 2 + 65536, hipHostMallocDefault));
+            c->stage_bytes[p] = need + need / 2 + 65536;
+        }
+        char* st = (char*)c->stage[p]; size_t at = 0;
+        auto push = [&](void* dev, const void* src, size_t bytes) -> int { // stage, then copy on the upload stream
+            if (!bytes) return MQ_OK;
+            if (src) memcpy(st + at, src, bytes);
+            HIPCHK(c, hipMemcpyAsync(dev, st + at, bytes, hipMemcpyHostToDevice, c->up_stream));
+            at += al(bytes);
+            return MQ_OK;
+        };
+        { // the per-frame tree with the indices of region p (the host mirror c->nodes / c->leaves keeps the contiguous numbering)
+            MqNode* sn = (MqNode*)(st + at);
+            for (size_t j = 0; j < nd; j++) { MqNode n = d_nodes[j]; n.child_base += (uint32_t)on; n.tri_base += (uint32_t)ol; sn[j] = n; }
+            if ((r = push((MqNode*)c->d_nodes.p + on, nullptr, nd * sizeof(MqNode)))) return r;
+            if ((r = push((MqTri*)c->d_tris.p + ot, d_tris.data(), td * sizeof(MqTri)))) return r;
+            MqLeafRec* sl = (MqLeafRec*)(st + at);
+            for (size_t j = 0; j < ld; j++) { MqLeafRec q = d_leaves[j]; q.tri0 += (uint32_t)ot; sl[j] = q; }
+            if ((r = push((MqLeafRec*)c->d_leaves.p + ol, nullptr, ld * sizeof(MqLeafRec)))) return r;
+            std::vector<MqShadeRec> recs;
+            shade_records(c, c->tris.data() + ts, td, recs);
+            if ((r = push((MqShadeRec*)c->d_shade.p + ot, recs.data(), td * sizeof(MqShadeRec)))) return r;
+        }
+        for (int sl = 0; sl < MQ_MAX_GEOMETRIES; sl++) { // per-slot arrays of region p
+            MqHostGeo& g = c->geo[sl];
+            if (g.flags & MQ_GEO_STATIC) continue;
+            c->scene.geo[sl].ext = nullptr; c->scene.geo[sl].idx = nullptr; c->scene.geo[sl].prev_vtx = nullptr;
+            if (!g.n_tri()) continue;
+            DevBuf& be = p ? c->d_ext_b[sl] : c->d_ext[sl]; DevBuf& bi = p ? c->d_idx_b[sl] : c->d_idx[sl]; DevBuf& bp = p ? c->d_prev_b[sl] : c->d_prev[sl];
+            auto room = [&](DevBuf& b, size_t bytes) -> int { return (!b.p || b.bytes < bytes) ? dev_alloc(c, b, bytes + bytes / 2 + 4096) : MQ_OK; };
+            if ((r = room(be, g.ext.size() * sizeof(mq_ext)))) return r;
+            if ((r = push(be.p, g.ext.data(), g.ext.size() * sizeof(mq_ext)))) return r;
+            c->scene.geo[sl].ext = (const mq_ext*)be.p;
+            if (g.dynamic) {
+                if ((r = room(bi, g.idx.size() * 4)) || (r = room(bp, g.prev_vtx.size() * 4))) return r;
+                if ((r = push(bi.p, g.idx.data(), g.idx.size() * 4)) || (r = push(bp.p, g.prev_vtx.data(), g.prev_vtx.size() * 4))) return r;
+                c->scene.geo[sl].idx = (const uint32_t*)bi.p; c->scene.geo[sl].prev_vtx = (const float*)bp.p;
+            }
+        }
+        HIPCHK(c, hipEventRecord(c->ev_uploaded, c->up_stream));
+        if (times) fprintf(stderr, "commit (per-frame, region %d): build %.3f ms, wait for the region's last reader %.3f, for the upload stream %.3f, stage + enqueue copies %.3f\n", p, ms(t_commit, t_a), ms(t_a, t_b), ms(t_b, t_c), ms(t_c, now()));
+        c->uploaded_valid = true;
+        c->scene.n_nodes = (uint32_t)(on + nd); c->scene.n_tris = (uint32_t)(ot + td);
+        c->scene.dyn_root = nd ? (uint32_t)on : MQ_NIL;
+        c->dyn_parity = p;
+        c->commits_dynamic++; c->commits_async++;
+        return MQ_OK;
+    }
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->up_stream) { c->scene_used_valid[0] = c->scene_used_valid[1] = false; c->scene_used_mixed[0] = c->scene_used_mixed[1] = false; }
+    if (partial && (ns == 0 || (force_sync && fits)) && c->dyn_parity == 0 && c->d_nodes.bytes >= c->nodes.size() * sizeof(MqNode) && c->d_tris.bytes >= c->tris.size() * sizeof(MqTri) && c->d_shade.bytes >= c->tris.size() * sizeof(MqShadeRec)
+        && c->d_leaves.bytes >= c->leaves.size() * sizeof(MqLeafRec)) { // per-frame geometry without a static tree: in place, behind a synchronisation
         std::vector<MqShadeRec> recs;
         shade_records(c, c->tris.data() + ts, td, recs);
         if (nd) HIPCHK(c, hipMemcpy((MqNode*)c->d_nodes.p + ns, c->nodes.data() + ns, nd * sizeof(MqNode), hipMemcpyHostToDevice));
@@ -819,12 +947,15 @@ int mq_scene_commit(mq_ctx* c) {
     c->dev_scene_valid = false;
     free_scene_dev(c);
     memset(&c->scene, 0, sizeof c->scene); c->scene.dyn_root = MQ_NIL;
-    // room for the per-frame part to grow without another full upload
-    const size_t slack_tris = td + 16384, slack_nodes = nd + 8192;
+    // two regions for the per-frame part (see above), each with room to grow without another full upload; the first holds the
+    // part committed now, right behind the static part -- the layout of the host mirror
+    const size_t cap_tris = td + 16384, cap_nodes = nd + 8192;
+    const size_t slack_tris = 2 * cap_tris - td, slack_nodes = 2 * cap_nodes - nd;
     if ((r = dev_alloc(c, c->d_nodes, (c->nodes.size() + slack_nodes) * sizeof(MqNode)))) return r;
     if ((r = dev_alloc(c, c->d_tris, (c->tris.size() + slack_tris) * sizeof(MqTri)))) return r;
     if ((r = dev_alloc(c, c->d_leaves, (c->leaves.size() + slack_tris) * sizeof(MqLeafRec)))) return r; // (at most one record per triangle)
     if (!c->leaves.empty()) HIPCHK(c, hipMemcpy(c->d_leaves.p, c->leaves.data(), c->leaves.size() * sizeof(MqLeafRec), hipMemcpyHostToDevice));
+    c->dyn_cap_nodes = (uint32_t)cap_nodes; c->dyn_cap_tris = (uint32_t)cap_tris; c->dyn_parity = 0;
     if ((r = dev_alloc(c, c->d_shade, (c->tris.size() + slack_tris) * sizeof(MqShadeRec)))) return r;
     if (!c->nodes.empty()) HIPCHK(c, hipMemcpy(c->d_nodes.p, c->nodes.data(), c->nodes.size() * sizeof(MqNode), hipMemcpyHostToDevice));
     if (!c->tris.empty()) HIPCHK(c, hipMemcpy(c->d_tris.p, c->tris.data(), c->tris.size() * sizeof(MqTri), hipMemcpyHostToDevice));
@@ -901,6 +1032,12 @@ int mq_scene_layout(const mq_ctx* c, uint64_t* static_nodes, uint64_t* static_tr
 int mq_scene_commit_counts(const mq_ctx* c, uint32_t* full, uint32_t* per_frame) {
     if (!c) return MQ_EINVAL;
     if (full) *full = c->commits_full; if (per_frame) *per_frame = c->commits_dynamic;
+    return MQ_OK;
+}
+
+int mq_scene_commit_async_count(const mq_ctx* c, uint32_t* n) {
+    if (!c || !n) return MQ_EINVAL;
+    *n = c->commits_async;
     return MQ_OK;
 }
 
@@ -1151,6 +1288,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->params_dirty) props_to_params(c);
     { int r = ensure_queue(c); if (r) return r; }
+    { int r = scene_ready(c, s); if (r) return r; }
     if (c->params.lc_lock_protocol && !c->d_lc_stats.p) { // statistics start at zero when they are switched on
         int r = dev_alloc(c, c->d_lc_stats, (size_t)c->lc_total * 8); if (!r) r = dev_alloc(c, c->d_last_upd, (size_t)c->mc_total * 4); if (r) return r;
         HIPCHK(c, hipMemsetAsync(c->d_lc_stats.p, 0, c->d_lc_stats.bytes, s)); HIPCHK(c, hipMemsetAsync(c->d_last_upd.p, 0, c->d_last_upd.bytes, s));
@@ -1231,6 +1369,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     const uint32_t parity = c->frame_parity & 1u;
     c->ev_pt_timed[slot] = overlap_pt && detail;
     if (overlap_pt) {
+        { int r = scene_ready(c, c->pt_stream); if (r) return r; }
         if (c->shaded_valid[parity]) HIPCHK(c, hipStreamWaitEvent(c->pt_stream, c->ev_shaded[parity], 0));
         if (behind_bounces && c->bounced_valid) HIPCHK(c, hipStreamWaitEvent(c->pt_stream, c->ev_bounced, 0));
         if (detail) HIPCHK(c, hipEventRecord(c->ev_pt_t[slot][0], c->pt_stream));
@@ -1330,6 +1469,7 @@ int mq_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) {
     // the first-hit kernel has read this parity's hit buffer (recorded here, at the end of the frame, rather than behind that
     // kernel: an event between two dependent launches costs ~5 us, and the camera rays that wait for it are two frames away)
     if (overlap_pt) { HIPCHK(c, hipEventRecord(c->ev_shaded[parity], s)); c->shaded_valid[parity] = true; }
+    { int r = scene_used(c, s); if (r) return r; }
     c->frame_parity++;
     c->ev_rounds[slot] = timed;
     c->ev_pending[slot] = true; c->ev_last = slot; c->ev_slot = (slot + 1) % mq_ctx::EV_RING;
@@ -1489,9 +1629,11 @@ static int ensure_band_gbuffer(mq_ctx* c, const mq_uniform* u, hipStream_t s) {
     F.gbuffer_only = 1u;
     F.prim_hits = (uint4*)c->d_band_hits.p; F.cam_spill = (unsigned long long*)c->d_cam_spill[1].p;
     if (F.n_local_tiles) {
+        { int r = scene_ready(c, s); if (r) return r; }
         int e = mq_launch_primary_trace(c->scene, c->params, F, false, (int)((F.slot_end + 255u) / 256u), s);
         if (!e) e = mq_launch_primary(c->scene, c->params, F, false, false, (int)((F.slot_end + F.shade_block - 1) / F.shade_block), s);
         if (e) return fail(c, MQ_EHIP, std::string("band g-buffer launch: ") + hipGetErrorString((hipError_t)e));
+        { int r = scene_used(c, s); if (r) return r; }
     }
     c->band_gb_valid = true;
     return MQ_OK;
@@ -1510,6 +1652,7 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
     c->last_stream = s;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->params_dirty) props_to_params(c);
+    { int r = scene_ready(c, s); if (r) return r; }
     const MqProps& q = c->props;
     if (!c->restir_seeded) { // pipeline (re)creation, renderer_restir.cpp:152-158
         if (q.restir_randomize_seed) { std::random_device dev; std::mt19937 rng(dev()); c->props.restir_seed = (uint32_t)rng(); }
@@ -1589,7 +1732,7 @@ int mq_restir_process(mq_ctx* c, const mq_uniform* u, int render, void* stream) 
     if (r1 > r0) HIPCHK(c, hipMemcpyAsync((char*)c->d_restir_prev.p + r0 * 64, (const char*)out + r0 * 64, (r1 - r0) * 64, hipMemcpyDeviceToDevice, s));
     if (g1 > g0) HIPCHK(c, hipMemcpyAsync((char*)c->d_restir_prev_gb.p + g0 * 16, (const char*)c->d_out[MQ_OUT_GBUFFER].p + g0 * 16, (g1 - g0) * 16, hipMemcpyDeviceToDevice, s));
     c->restir_iteration++;
-    return MQ_OK;
+    return scene_used(c, s);
 }
 
 // ---- post chain (mq_post.hip): accum + volume accum + add ------------------------------------------------------
@@ -1758,11 +1901,16 @@ int mq_trace_rays(mq_ctx* c, const float* org, const float* dir, uint32_t n, uin
     if (!r) r = dev_alloc(c, d_t, (size_t)n * 4);
     if (!r) r = dev_alloc(c, d_uv, (size_t)n * 8);
     if (!r) r = dev_alloc(c, d_sp, (size_t)grid * 256 * mq_spill_entries() * 8);
+    if (!r) r = scene_ready(c, nullptr);
     if (!r) { int e = mq_launch_trace(c->scene, (const float*)d_o.p, (const float*)d_d.p, n, (uint32_t*)d_p.p, (float*)d_t.p, (float*)d_uv.p, (unsigned long long*)d_sp.p, grid, nullptr); if (e) r = fail(c, MQ_EHIP, std::string("trace launch: ") + hipGetErrorString((hipError_t)e)); }
     if (!r && hipDeviceSynchronize() != hipSuccess) r = fail(c, MQ_EHIP, "trace kernel failed");
     if (!r && hipMemcpy(prim, d_p.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
     if (!r && hipMemcpy(t, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
     if (!r && uv && hipMemcpy(uv, d_uv.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
+    if (!r && c->dyn_parity) { // triangle numbers as in mq_scene_get_bvh: the per-frame triangles follow the static ones (on the device they sit in the second region)
+        const uint32_t first = c->dev_static_tris + c->dyn_cap_tris;
+        for (uint32_t i = 0; i < n; i++) if (prim[i] != MQ_NIL && prim[i] >= first) prim[i] -= c->dyn_cap_tris;
+    }
     dev_free(d_o); dev_free(d_d); dev_free(d_p); dev_free(d_t); dev_free(d_uv); dev_free(d_sp);
     return r;
 }
@@ -1778,6 +1926,7 @@ int mq_math_eval(mq_ctx* c, int op, const float* in, float* out, uint32_t n) {
     DevBuf d_in, d_out; int r = 0;
     if (!r) r = dev_upload(c, d_in, in, (size_t)n * ni * 4);
     if (!r) r = dev_alloc(c, d_out, (size_t)n * no * 4);
+    if (!r) r = scene_ready(c, nullptr);
     if (!r) { int e = mq_launch_math(c->scene, c->params, op, ni, no, (const float*)d_in.p, (float*)d_out.p, n, nullptr); if (e) r = fail(c, MQ_EHIP, std::string("math launch: ") + hipGetErrorString((hipError_t)e)); }
     if (!r && hipDeviceSynchronize() != hipSuccess) r = fail(c, MQ_EHIP, "math kernel failed");
     if (!r && hipMemcpy(out, d_out.p, (size_t)n * no * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");

@@ -9,6 +9,11 @@
 #include "mq_host.h"
 
 #include <algorithm>
+#include <functional>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -36,7 +41,58 @@ struct AABB {
 #ifndef MQ_BVH_LEAF
 #define MQ_BVH_LEAF 3
 #endif
-struct BNode { AABB box; int left = -1, right = -1; uint32_t first = 0, count = 0; };
+struct BNode { AABB box; int left = -1, right = -1; uint32_t first = 0, count = 0 /* leaves only */, ntris = 0 /* below this node */; };
+
+// A small pool of worker threads for the builder's subtree tasks (created on first use, lives as long as the process).  The
+// thread that builds helps until its own tasks are done, so a build never waits for a worker that is busy elsewhere.
+// Size: MQ_BVH_THREADS, else one per hardware thread up to 16 (a GPU box gives a job about 16 cores' worth of time).
+struct TaskGroup { std::atomic<int> pending{0}; };
+class TaskPool {
+public:
+    static TaskPool& get() { static TaskPool p; return p; }
+    int threads() const { return (int)workers.size() + 1; }
+    void spawn(TaskGroup& g, std::function<void()> f) {
+        g.pending.fetch_add(1, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> l(m); q.emplace_back(&g, std::move(f)); }
+        cv.notify_one();
+    }
+    void wait(TaskGroup& g) { // run queued tasks (of any group) until this group has none left
+        std::unique_lock<std::mutex> l(m);
+        while (g.pending.load(std::memory_order_acquire) != 0) {
+            if (!q.empty()) { run_one(l); continue; }
+            done.wait_for(l, std::chrono::microseconds(200));
+        }
+    }
+private:
+    std::vector<std::thread> workers;
+    std::mutex m; std::condition_variable cv, done;
+    std::deque<std::pair<TaskGroup*, std::function<void()>>> q;
+    bool stop = false;
+    void run_one(std::unique_lock<std::mutex>& l) {
+        auto t = std::move(q.front()); q.pop_front();
+        l.unlock();
+        t.second();
+        const bool last = t.first->pending.fetch_sub(1, std::memory_order_acq_rel) == 1;
+        l.lock();
+        if (last) done.notify_all();
+    }
+    TaskPool() {
+        int n = getenv("MQ_BVH_THREADS") ? atoi(getenv("MQ_BVH_THREADS")) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        for (int i = 1; i < n; i++) workers.emplace_back([this] {
+            std::unique_lock<std::mutex> l(m);
+            for (;;) {
+                cv.wait(l, [this] { return stop || !q.empty(); });
+                if (stop) return;
+                run_one(l);
+            }
+        });
+    }
+    ~TaskPool() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+    }
+};
 
 struct Builder {
     const std::vector<MqTri>& in;
@@ -44,74 +100,91 @@ struct Builder {
     std::vector<float> cent; // 3 per tri
     std::vector<uint32_t> order;
     std::vector<BNode> nodes; // preallocated, 2 per triangle: a subtree over `count` triangles owns the ids [id, id + 2 * count - 1)
+    TaskGroup group;
+    uint32_t spawn_min = 0;   // subtrees of at least this many triangles become tasks of the pool (0: single-threaded build)
 
     explicit Builder(const std::vector<MqTri>& t) : in(t) {}
 
-    int build(uint32_t first, uint32_t count, int depth, int id) {
-        AABB box; box.reset();
-        AABB cbox; cbox.reset();
-        for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[order[i]]); cbox.grow(&cent[3 * order[i]]); }
-        nodes[id].box = box;
-        if (count <= MQ_BVH_LEAF) { nodes[id].first = first; nodes[id].count = count; return id; }
-        // binned SAH over the three axes, 16 bins
-        const int NB = 16;
-        int best_axis = -1, best_split = 0; float best_cost = INFINITY;
-        if (depth < 48) for (int a = 0; a < 3; a++) {
-            float ext = cbox.hi[a] - cbox.lo[a];
-            if (!(ext > 0.0f)) continue;
-            AABB bb[NB]; uint32_t bc[NB];
-            for (int b = 0; b < NB; b++) { bb[b].reset(); bc[b] = 0; }
-            float scale = NB / ext;
-            for (uint32_t i = first; i < first + count; i++) {
-                int b = std::min(NB - 1, std::max(0, (int)((cent[3 * order[i] + a] - cbox.lo[a]) * scale)));
-                bb[b].grow(tbox[order[i]]); bc[b]++;
+    // Binned SAH over the three axes, 16 bins, the three axes binned in ONE pass over the triangles.  The two halves of a split
+    // touch disjoint ranges of `order` and their own node ids (known before they are built), so large halves are handed to the
+    // pool; the tree does not depend on who built what.
+    void build(uint32_t first, uint32_t count, int depth, int id) {
+        for (;;) {
+            AABB box; box.reset();
+            AABB cbox; cbox.reset();
+            for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[order[i]]); cbox.grow(&cent[3 * order[i]]); }
+            nodes[id].box = box; nodes[id].ntris = count;
+            if (count <= MQ_BVH_LEAF) { nodes[id].first = first; nodes[id].count = count; return; }
+            const int NB = 16;
+            int best_axis = -1, best_split = 0; float best_cost = INFINITY;
+            if (depth < 48) {
+                AABB bb[3][NB]; uint32_t bc[3][NB];
+                float scale[3]; bool use[3];
+                for (int a = 0; a < 3; a++) {
+                    const float ext = cbox.hi[a] - cbox.lo[a];
+                    use[a] = ext > 0.0f; scale[a] = use[a] ? NB / ext : 0.0f;
+                    for (int b = 0; b < NB; b++) { bb[a][b].reset(); bc[a][b] = 0; }
+                }
+                for (uint32_t i = first; i < first + count; i++) {
+                    const uint32_t t = order[i];
+                    const AABB& tb = tbox[t];
+                    for (int a = 0; a < 3; a++) if (use[a]) {
+                        const int b = std::min(NB - 1, std::max(0, (int)((cent[3 * t + a] - cbox.lo[a]) * scale[a])));
+                        bb[a][b].grow(tb); bc[a][b]++;
+                    }
+                }
+                for (int a = 0; a < 3; a++) {
+                    if (!use[a]) continue;
+                    float rarea[NB]; uint32_t rcount[NB];
+                    AABB acc; acc.reset(); uint32_t cn = 0;
+                    for (int b = NB - 1; b > 0; b--) { acc.grow(bb[a][b]); cn += bc[a][b]; rarea[b] = acc.area(); rcount[b] = cn; }
+                    acc.reset(); cn = 0;
+                    for (int b = 0; b < NB - 1; b++) {
+                        acc.grow(bb[a][b]); cn += bc[a][b];
+                        if (cn == 0 || rcount[b + 1] == 0) continue;
+                        float cost = acc.area() * (float)cn + rarea[b + 1] * (float)rcount[b + 1];
+                        if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = b; }
+                    }
+                }
             }
-            float rarea[NB]; uint32_t rcount[NB];
-            AABB acc; acc.reset(); uint32_t cn = 0;
-            for (int b = NB - 1; b > 0; b--) { acc.grow(bb[b]); cn += bc[b]; rarea[b] = acc.area(); rcount[b] = cn; }
-            acc.reset(); cn = 0;
-            for (int b = 0; b < NB - 1; b++) {
-                acc.grow(bb[b]); cn += bc[b];
-                if (cn == 0 || rcount[b + 1] == 0) continue;
-                float cost = acc.area() * (float)cn + rarea[b + 1] * (float)rcount[b + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = b; }
+            uint32_t mid;
+            if (best_axis >= 0) {
+                float ext = cbox.hi[best_axis] - cbox.lo[best_axis];
+                float scale = NB / ext, lo = cbox.lo[best_axis];
+                int a = best_axis, sp = best_split;
+                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                    int b = std::min(NB - 1, std::max(0, (int)((cent[3 * t + a] - lo) * scale)));
+                    return b <= sp;
+                });
+                mid = (uint32_t)(it - order.begin());
+            } else mid = first; // force the median split below
+            if (mid == first || mid == first + count) { // degenerate: median split on the widest axis
+                int a = 0; float e0 = cbox.hi[0] - cbox.lo[0], e1 = cbox.hi[1] - cbox.lo[1], e2 = cbox.hi[2] - cbox.lo[2];
+                if (e1 > e0 && e1 >= e2) a = 1; else if (e2 > e0 && e2 > e1) a = 2;
+                mid = first + count / 2;
+                std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                                 [&](uint32_t x, uint32_t y) { float cx = cent[3 * x + a], cy = cent[3 * y + a]; return cx < cy || (cx == cy && x < y); });
             }
+            const uint32_t lc = mid - first, rc = first + count - mid;
+            const int l = id + 1, r = id + 2 * (int)lc;
+            nodes[id].left = l; nodes[id].right = r;
+            if (spawn_min && lc >= spawn_min) { const uint32_t f0 = first; const int d1 = depth + 1; TaskPool::get().spawn(group, [this, f0, lc, d1, l] { build(f0, lc, d1, l); }); }
+            else build(first, lc, depth + 1, l);
+            first = mid; count = rc; depth++; id = r; // the right half: this thread goes on
         }
-        uint32_t mid;
-        if (best_axis >= 0) {
-            float ext = cbox.hi[best_axis] - cbox.lo[best_axis];
-            float scale = NB / ext, lo = cbox.lo[best_axis];
-            int a = best_axis, sp = best_split;
-            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
-                int b = std::min(NB - 1, std::max(0, (int)((cent[3 * t + a] - lo) * scale)));
-                return b <= sp;
-            });
-            mid = (uint32_t)(it - order.begin());
-        } else mid = first; // force the median split below
-        if (mid == first || mid == first + count) { // degenerate: median split on the widest axis
-            int a = 0; float e0 = cbox.hi[0] - cbox.lo[0], e1 = cbox.hi[1] - cbox.lo[1], e2 = cbox.hi[2] - cbox.lo[2];
-            if (e1 > e0 && e1 >= e2) a = 1; else if (e2 > e0 && e2 > e1) a = 2;
-            mid = first + count / 2;
-            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
-                             [&](uint32_t x, uint32_t y) { float cx = cent[3 * x + a], cy = cent[3 * y + a]; return cx < cy || (cx == cy && x < y); });
-        }
-        // the two halves touch disjoint ranges of `order` and their own nodes: the upper levels fork (the collapse
-        // below walks the links, so the result does not depend on which task numbered a node)
-        int l, r;
-        static const int fork_depth = getenv("MQ_BVH_FORK_DEPTH") ? atoi(getenv("MQ_BVH_FORK_DEPTH")) : 5; // 0: single-threaded build
-        if (depth < fork_depth && count >= 4096) {
-            auto left = std::async(std::launch::async, [this, first, mid, depth, id] { return build(first, mid - first, depth + 1, id + 1); });
-            r = build(mid, first + count - mid, depth + 1, id + 2 * (int)(mid - first));
-            l = left.get();
-        } else {
-            l = build(first, mid - first, depth + 1, id + 1);
-            r = build(mid, first + count - mid, depth + 1, id + 2 * (int)(mid - first));
-        }
-        nodes[id].left = l; nodes[id].right = r;
-        return id;
     }
 };
 
+} // namespace
+void mq_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& f) {
+    static const bool serial = getenv("MQ_BVH_FORK_DEPTH") && atoi(getenv("MQ_BVH_FORK_DEPTH")) == 0;
+    if (grain == 0) grain = 1;
+    if (serial || n <= grain || TaskPool::get().threads() == 1) { if (n) f(0, n); return; }
+    TaskGroup g;
+    for (size_t b = 0; b < n; b += grain) { const size_t e = std::min(n, b + grain); TaskPool::get().spawn(g, [&f, b, e] { f(b, e); }); }
+    TaskPool::get().wait(g);
+}
+namespace {
 inline float exp2i(int e) { uint32_t b = (uint32_t)(e + 127) << 23; float f; memcpy(&f, &b, 4); return f; }
 
 } // namespace
@@ -169,44 +242,51 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
     Builder B(tris);
     B.tbox.resize(n); B.cent.resize(3 * (size_t)n); B.order.resize(n);
     float maxabs = 1.0f;
-    for (uint32_t i = 0; i < n; i++) {
-        AABB b; b.reset();
-        b.grow(tris[i].v0); b.grow(tris[i].v1); b.grow(tris[i].v2);
-        B.tbox[i] = b;
-        for (int a = 0; a < 3; a++) {
-            B.cent[3 * (size_t)i + a] = 0.5f * (b.lo[a] + b.hi[a]);
-            maxabs = std::max(maxabs, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
-            if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) { err = "non-finite vertex"; return false; }
-        }
-        B.order[i] = i;
+    {
+        std::mutex mm; bool bad = false;
+        mq_parallel_for(n, 8192, [&](size_t b0, size_t b1) {
+            float mx = 1.0f; bool nf = false;
+            for (size_t i = b0; i < b1; i++) {
+                AABB b; b.reset();
+                b.grow(tris[i].v0); b.grow(tris[i].v1); b.grow(tris[i].v2);
+                B.tbox[i] = b;
+                for (int a = 0; a < 3; a++) {
+                    B.cent[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]);
+                    mx = std::max(mx, std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+                    if (!std::isfinite(b.lo[a]) || !std::isfinite(b.hi[a])) nf = true;
+                }
+                B.order[i] = (uint32_t)i;
+            }
+            std::lock_guard<std::mutex> l(mm); maxabs = std::max(maxabs, mx); bad = bad || nf;
+        });
+        if (bad) { err = "non-finite vertex"; return false; }
     }
     const float pad = std::max(1e-4f, maxabs * 4.76837158203125e-07f); // 2^-21 * extent
     B.nodes.resize(2 * (size_t)n);
     auto T0 = std::chrono::steady_clock::now();
-    int root = B.build(0, n, 0, 0);
+    static const int fork_depth = getenv("MQ_BVH_FORK_DEPTH") ? atoi(getenv("MQ_BVH_FORK_DEPTH")) : 5; // 0: single-threaded build
+    B.spawn_min = (fork_depth > 0 && n >= 2048 && TaskPool::get().threads() > 1) ? std::max(512u, n / 256u) : 0u;
+    B.build(0, n, 0, 0);
+    if (B.spawn_min) TaskPool::get().wait(B.group);
+    const int root = 0;
     auto T1 = std::chrono::steady_clock::now();
 
     // ---- collapse to 8-wide ---------------------------------------------------------------------
-    struct Work { int bnode; uint32_t out_index; uint32_t depth; };
-    uint32_t max_depth = 0;
     // Order in which nodes are expanded = order of their child blocks (and of their triangles and shading records) in
     // memory.  Depth first: a subtree's blocks are neighbours, so a ray walking down finds its next nodes in lines it
     // has just touched (-0.5 % frame time against breadth first, MQ_BVH_ORDER=bfs, which spreads a path over the levels).
-    std::deque<Work> q;
+    // Depth first also makes everything below a node ONE contiguous range of each output array, so subtrees of at most
+    // COLLAPSE_PART triangles are collapsed by tasks of the pool into arrays of their own (indices relative to the subtree)
+    // and spliced in where the walk over the top of the tree reaches them: the same arrays as one walk over everything.
+    struct Work { int bnode; uint32_t out_index; uint32_t depth; };
+    struct Collapsed { std::vector<MqNode> nodes; std::vector<MqLeafRec> leaves; std::vector<MqTri> tris; double sah = 0.0; uint32_t max_depth = 0; };
     static const bool dfs_order = !(getenv("MQ_BVH_ORDER") && !strcmp(getenv("MQ_BVH_ORDER"), "bfs"));
-    out_nodes.emplace_back();
-    q.push_back({root, 0, 1});
-    out_tris.reserve(n);
-    double sah = 0.0;
     const float root_area = std::max(B.nodes[root].box.area(), 1e-30f);
-    while (!q.empty()) {
-        Work w;
-        if (dfs_order) { w = q.back(); q.pop_back(); } else { w = q.front(); q.pop_front(); }
-        max_depth = std::max(max_depth, w.depth);
-        // gather up to 8 children: repeatedly open the internal child with the largest area
-        int ch[8]; int nc = 0;
-        const BNode& bn = B.nodes[w.bnode];
-        if (bn.count > 0) { ch[nc++] = w.bnode; } // root that is a leaf
+    // up to 8 children of a wide node: repeatedly open the internal child with the largest area
+    auto gather = [&](int bnode, int ch[8]) -> int {
+        int nc = 0;
+        const BNode& bn = B.nodes[bnode];
+        if (bn.count > 0) { ch[nc++] = bnode; } // root that is a leaf
         else { ch[nc++] = bn.left; ch[nc++] = bn.right; }
         for (;;) {
             if (nc >= 8) break;
@@ -219,6 +299,37 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
             int open = ch[best];
             ch[best] = B.nodes[open].left; ch[nc++] = B.nodes[open].right;
         }
+        return nc;
+    };
+    const uint32_t COLLAPSE_PART = 1024;
+    std::vector<int> part_root;            // binary nodes whose subtrees are collapsed on their own
+    std::vector<Collapsed> parts;
+    std::vector<int> part_of(dfs_order && n >= 4 * COLLAPSE_PART ? B.nodes.size() : 0, -1); // (the splice relies on the depth-first order)
+    auto collapse = [&](int root_bnode, uint32_t depth0, Collapsed& out, bool splice) {
+    std::vector<MqNode>& out_nodes = out.nodes; std::vector<MqLeafRec>& out_leaves = out.leaves; std::vector<MqTri>& out_tris = out.tris;
+    double& sah = out.sah; uint32_t& max_depth = out.max_depth;
+    std::deque<Work> q;
+    out_nodes.emplace_back();
+    q.push_back({root_bnode, 0, depth0});
+    while (!q.empty()) {
+        Work w;
+        if (dfs_order) { w = q.back(); q.pop_back(); } else { w = q.front(); q.pop_front(); }
+        if (splice && part_of[w.bnode] >= 0) { // a subtree collapsed on its own: its root into the slot its parent reserved, the rest behind everything so far
+            const Collapsed& P = parts[part_of[w.bnode]];
+            const uint32_t node_off = (uint32_t)out_nodes.size() - 1u, leaf_off = (uint32_t)out_leaves.size(), tri_off = (uint32_t)out_tris.size();
+            for (size_t k = 0; k < P.nodes.size(); k++) {
+                MqNode nd = P.nodes[k]; nd.child_base += node_off; nd.tri_base += leaf_off;
+                if (k == 0) out_nodes[w.out_index] = nd; else out_nodes.push_back(nd);
+            }
+            for (MqLeafRec l : P.leaves) { l.tri0 += tri_off; out_leaves.push_back(l); }
+            out_tris.insert(out_tris.end(), P.tris.begin(), P.tris.end());
+            sah += P.sah; max_depth = std::max(max_depth, P.max_depth);
+            continue;
+        }
+        max_depth = std::max(max_depth, w.depth);
+        int ch[8];
+        const BNode& bn = B.nodes[w.bnode];
+        const int nc = gather(w.bnode, ch);
         // octant-aware slot assignment: slot bit k set = child lies on the high side of axis k
         AABB pb = bn.box;
         float pc[3] = {0.5f * (pb.lo[0] + pb.hi[0]), 0.5f * (pb.lo[1] + pb.hi[1]), 0.5f * (pb.lo[2] + pb.hi[2])};
@@ -292,7 +403,31 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
         }
         out_nodes[w.out_index] = node;
     }
-    if (getenv("MQ_DEBUG_BUILD_TIMES")) fprintf(stderr, "bvh build: %u tris, binary tree %.1f ms, collapse %.1f ms\n", n, std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T1).count());
+    }; // collapse
+    if (!part_of.empty()) {
+        std::vector<std::pair<int, uint32_t>> st; st.push_back({root, 1u});
+        std::vector<uint32_t> part_depth;
+        while (!st.empty()) { // the top of the tree: which subtrees are small enough to go to a task, and at which depth they hang
+            const auto [b, d] = st.back(); st.pop_back();
+            if (B.nodes[b].ntris <= COLLAPSE_PART) { part_of[b] = (int)part_root.size(); part_root.push_back(b); part_depth.push_back(d); continue; }
+            int ch[8]; const int nc = gather(b, ch);
+            for (int i = 0; i < nc; i++) if (B.nodes[ch[i]].count == 0) st.push_back({ch[i], d + 1});
+        }
+        parts.resize(part_root.size());
+        TaskGroup cg;
+        const bool pool = B.spawn_min != 0;
+        for (size_t k = 0; k < part_root.size(); k++) {
+            auto job = [&, k] { parts[k].tris.reserve(B.nodes[part_root[k]].ntris); collapse(part_root[k], part_depth[k], parts[k], false); };
+            if (pool) TaskPool::get().spawn(cg, job); else job();
+        }
+        if (pool) TaskPool::get().wait(cg);
+    }
+    Collapsed all;
+    all.tris.reserve(n);
+    collapse(root, 1, all, !part_of.empty());
+    out_nodes.swap(all.nodes); out_leaves.swap(all.leaves); out_tris.swap(all.tris);
+    const double sah = all.sah; const uint32_t max_depth = all.max_depth;
+    if (getenv("MQ_DEBUG_BUILD_TIMES")) fprintf(stderr, "bvh build: %u tris on %d threads, binary tree %.1f ms, collapse %.1f ms\n", n, TaskPool::get().threads(), std::chrono::duration<double, std::milli>(T1 - T0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T1).count());
     if (sah_cost) *sah_cost = (float)sah;
     if (depth_out) *depth_out = max_depth; // levels of 8-wide nodes
     if (out_tris.size() != n) { err = "internal: triangle count mismatch after collapse"; return false; }

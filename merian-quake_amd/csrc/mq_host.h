@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <string>
 #include <vector>
+#include <functional>
 
 #include "mq_types.h"
 
@@ -102,6 +103,8 @@ struct MqProps {
     bool quirk_n16_wrap = true;    // mc.glsl:26 `N * N` on a uint16_t (grid.h:19): wraps, 0 at N = 256 / 512 / 768 / 1024
 };
 
+// f(begin, end) over [0, n) in chunks of about `grain`, on the builder's worker pool (mq_bvh.cpp); the caller takes part.  Chunks must be independent.
+void mq_parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& f);
 bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nodes, std::vector<MqTri>& out_tris, std::vector<MqLeafRec>& out_leaves, float* sah_cost, std::string& err, uint32_t* depth_out = nullptr);
 
 struct mq_ctx;

@@ -148,7 +148,11 @@ int mq_dyn_add_particles(mq_ctx* ctx, const mq_particle* parts, uint32_t n, cons
     MqHostGeo& g = P.pending;
     static const V3 voff[4] = {{0.0f, 1.0f, 0.0f}, {-0.5f, -0.5f, 0.87f}, {-0.5f, -0.5f, -0.87f}, {1.0f, -0.5f, 0.0f}};
     const V3 vpn = {view->forward[0], view->forward[1], view->forward[2]}, r_origin = {view->origin[0], view->origin[1], view->origin[2]};
-    for (uint32_t pi = 0; pi < n; pi++) {
+    // every particle is a tetrahedron of its own (4 vertices, 4 triangles) with its own random stream: written in place, in parallel
+    const size_t v_at = g.vtx.size(), i_at = g.idx.size(), e_at = g.ext.size();
+    g.vtx.resize(v_at + 12 * (size_t)n); g.prev_vtx.resize(v_at + 12 * (size_t)n); g.idx.resize(i_at + 12 * (size_t)n); g.ext.resize(e_at + 4 * (size_t)n);
+    mq_parallel_for(n, 512, [&](size_t p_begin, size_t p_end) {
+    for (size_t pi = p_begin; pi < p_end; pi++) {
         const mq_particle& p = parts[pi];
         const V3 org = {p.org[0], p.org[1], p.org[2]}, prev_org = {p.prev_org[0], p.prev_org[1], p.prev_org[2]}, vel = {p.vel[0], p.vel[1], p.vel[2]};
         float scale = dot(org - r_origin, vpn); // from r_part.c
@@ -177,26 +181,31 @@ int mq_dyn_add_particles(mq_ctx* ctx, const mq_particle* parts, uint32_t n, cons
                 prev_vert[k] = (prev_org + V3{particle_offset, particle_offset, particle_offset}) + rodrigues(local, axis, prev_ang);
             }
         }
-        const uint32_t base = (uint32_t)(g.vtx.size() / 3);
-        for (int k = 0; k < 4; k++) push_vtx(g, vert[k], prev_vert[k]);
+        const uint32_t base = (uint32_t)(v_at / 3 + 4 * pi);
+        for (int k = 0; k < 4; k++) {
+            float* v = &g.vtx[v_at + 12 * pi + 3 * k]; float* q = &g.prev_vtx[v_at + 12 * pi + 3 * k];
+            v[0] = vert[k].x; v[1] = vert[k].y; v[2] = vert[k].z; q[0] = prev_vert[k].x; q[1] = prev_vert[k].y; q[2] = prev_vert[k].z;
+        }
         static const uint32_t tet[12] = {0, 1, 2, 0, 2, 3, 0, 3, 1, 1, 3, 2};
         for (int k = 0; k < 4; k++) {
             const uint32_t i0 = base + tet[3 * k], i1 = base + tet[3 * k + 1], i2 = base + tet[3 * k + 2];
-            g.idx.push_back(i0); g.idx.push_back(i1); g.idx.push_back(i2);
+            uint32_t* ix = &g.idx[i_at + 12 * pi + 3 * k]; ix[0] = i0; ix[1] = i1; ix[2] = i2;
+            mq_ext& ex = g.ext[e_at + 4 * pi + k];
             if (texnum) { // texture patch
                 const V3 a = vert[tet[3 * k]], b = vert[tet[3 * k + 1]], c = vert[tet[3 * k + 2]];
                 const uint32_t enc = encode_normal(normalize(cross(c - a, b - a)));
-                g.ext.push_back(make_ext((uint16_t)texnum, (uint16_t)texnum_fb, enc, enc, enc, 0, 1, 0, 0, 1, 0));
+                ex = make_ext((uint16_t)texnum, (uint16_t)texnum_fb, enc, enc, enc, 0, 1, 0, 0, 1, 0);
             } else { // solid colour (:193-211)
                 for (int i = 0; i < 3; i++) cb[0] = (uint8_t)std::min(255.0, std::max(0.0, cb[0] * (1 + xr.next() * 0.1 - 0.05)));
                 const uint32_t c = (uint32_t)cb[0] | ((uint32_t)cb[1] << 8) | ((uint32_t)cb[2] << 16) | ((uint32_t)cb[3] << 24);
                 const uint32_t c_orig = p.color_rgba;
                 const uint32_t c_fb = (0.299 * cb[0] + 0.587 * cb[1] + 0.114 * cb[2] > 150) ? c : 0u; // bright colours are probably emitting
                 (void)c_orig;
-                g.ext.push_back(make_ext(0, (uint16_t)(MQ_MAT_FLAGS_SOLID << 12), c, c_fb, 0, 0, 1, 0, 0, 1, 0));
+                ex = make_ext(0, (uint16_t)(MQ_MAT_FLAGS_SOLID << 12), c, c_fb, 0, 0, 1, 0, 0, 1, 0);
             }
         }
     }
+    });
     return MQ_OK;
 }
 

@@ -137,6 +137,7 @@ def load_library(path=None):
         "mq_timing_detail_frames": (i32, [P, C.POINTER(C.c_uint32)]),
         "mq_scene_layout": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mq_scene_commit_counts": (i32, [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "mq_scene_commit_async_count": (i32, [P, C.POINTER(C.c_uint32)]),
         "mq_scene_get_leaves": (i32, [P, C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "mq_scene_stats": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]),
         "mq_describe": (i32, [P, u32, u32, C.POINTER(IoDesc)]),
@@ -275,6 +276,11 @@ class Context:
         a, b = C.c_uint32(), C.c_uint32()
         self._chk(self.lib.mq_scene_commit_counts(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def commit_async_count(self):
+        a = C.c_uint32()
+        self._chk(self.lib.mq_scene_commit_async_count(self.h, C.byref(a)))
+        return a.value
 
     def set_constants(self, sun_color, sun_direction, fov=90.0, fov_tan_alpha_half=1.0, volume_max_t=1000.0):
         c = Constants((C.c_float * 3)(*sun_color), (C.c_float * 3)(*sun_direction), fov, fov_tan_alpha_half, volume_max_t)

@@ -287,3 +287,53 @@ def test_deep_traversal_stacks_with_overlapped_camera_rays(mqlib):
     assert a[0].view(np.float32).sum() > 0 and np.isfinite(a[0].view(np.float32)).all()
     for x, y in zip(a, b):
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
+def _particle_frames(mqlib, frames, sync_every_frame, overlap, W=480, H=300):
+    """`frames` frames with PER-FRAME geometry: a different cloud of particles (count and positions) committed before each."""
+    import mqhip
+    ctx = mqhip.Context(0)
+    ctx.header_defaults()
+    ctx.synth_scene("synth_start", 4)
+    for k, v in {"randomize seed": 0, "seed": 0x5EED, **SMALL, "reference mode": 1, "spp": 2, "max path length": 3, "overlap camera rays": overlap, "accum: alpha": 0.9}.items():
+        ctx.set_property(k, v)
+    ctx.commit(); ctx.connect(W, H)
+    rng = np.random.default_rng(77)
+    u0 = ctx.synth_camera(0)
+    eye = np.array([u0.cam_x[0], u0.cam_x[1], u0.cam_x[2]]); fwd = np.array([u0.cam_w[0], u0.cam_w[1], u0.cam_w[2]])
+    view = mqhip.View()
+    for k in range(3):
+        view.origin[k] = u0.cam_x[k]; view.forward[k] = u0.cam_w[k]; view.up[k] = u0.cam_u[k]
+    right = np.cross(fwd, np.array([u0.cam_u[0], u0.cam_u[1], u0.cam_u[2]]))
+    for k in range(3):
+        view.right[k] = right[k]
+    imgs = []
+    for f in range(frames):
+        n = 300 + 170 * (f % 4)  # the per-frame tree changes size from frame to frame
+        parts = np.zeros(n, mqhip.PARTICLE_DTYPE)
+        parts["org"] = eye + fwd * 40.0 + rng.uniform(-30, 30, (n, 3)); parts["prev_org"] = parts["org"] - rng.uniform(-2, 2, (n, 3))
+        parts["seed"] = rng.integers(1, 2 ** 32, n); parts["color_rgba"] = rng.choice([0x0000003c, 0x00ffffff, 0x0040a0ff], n); parts["type"] = rng.choice([0, 3, 5], n)
+        ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, f / 60.0, (f - 1) / 60.0); ctx.dyn_end(2)
+        ctx.commit()           # (asynchronous from the second per-frame commit on: the frames before it are still rendering)
+        ctx.process(u0); ctx.post_process()
+        if sync_every_frame:
+            ctx.sync()
+            imgs.append(ctx.read_output(mqhip.OUT_HITS).copy())
+    out = _outputs(ctx)
+    out["OUT_ACCUM"] = ctx.read_output(mqhip.OUT_ACCUM).copy()  # depends on EVERY frame of the sequence
+    stats = {"async": ctx.commit_async_count(), "per_frame": ctx.commit_counts()[1]}
+    ctx.close()
+    return out, imgs, stats
+
+
+@pytest.mark.parametrize("overlap", ["off", "auto"])
+def test_per_frame_geometry_commits_do_not_wait_and_do_not_race(mqlib, overlap):
+    """A commit of per-frame geometry goes to the region of the device arrays that the frames in flight do not read
+    (mq_api.cpp, mq_scene_commit) and does not wait for them: eight frames issued back to back, each with its own particles,
+    against the same eight frames with a device synchronisation behind every one -- every output of the last frame and the
+    image accumulated over all eight are bit-identical; and the particles do change the first hits from frame to frame."""
+    piped, _, stats = _particle_frames(mqlib, 8, False, overlap)
+    synced, hits, _ = _particle_frames(mqlib, 8, True, overlap)
+    _same(piped, synced, overlap)
+    assert not np.array_equal(hits[-1], hits[-2]) and not np.array_equal(hits[-2], hits[-3])
+    assert stats["async"] >= 6 and stats["per_frame"] == 8, stats
