@@ -126,6 +126,8 @@ struct mq_ctx {
     hipEvent_t ev_scene_used[2] = {nullptr, nullptr}; bool scene_used_valid[2] = {false, false}; // last launch that read region p
     hipStream_t scene_used_stream[2] = {nullptr, nullptr}; bool scene_used_mixed[2] = {false, false}; // (read from more than one stream: the commit falls back to a device synchronisation)
     uint32_t commits_async = 0;
+    std::vector<MqNode> pend_nodes; std::vector<MqTri> pend_tris; std::vector<MqLeafRec> pend_leaves; bool mirror_pending = false; // per-frame trees of the last asynchronous commit, not yet in nodes / tris / leaves
+    uint32_t n_dyn_nodes = 0, n_dyn_tris = 0, n_dyn_leaves = 0;
     // frame state
     bool connected = false;
     uint32_t W = 0, H = 0, tiles_x = 0, tiles_y = 0;
@@ -714,20 +716,33 @@ int mq_scene_get_texture(const mq_ctx* c, uint32_t texnum, uint32_t* w, uint32_t
     if (w) *w = t.w; if (h) *h = t.h; if (rgba8) *rgba8 = t.px.empty() ? nullptr : t.px.data(); if (flags) *flags = t.flags;
     return MQ_OK;
 }
+static void materialize_mirror(const mq_ctx* cc) { // (the inspection calls take a const context; the mirror is a cache)
+    mq_ctx* c = const_cast<mq_ctx*>(cc);
+    if (!c->mirror_pending) return;
+    const size_t ns = c->n_static_nodes, ts = c->n_static_tris, ls = c->n_static_leaves, nd = c->pend_nodes.size(), td = c->pend_tris.size(), ld = c->pend_leaves.size();
+    c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + ld);
+    for (size_t j = 0; j < nd; j++) { MqNode n = c->pend_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ls; c->nodes[ns + j] = n; }
+    std::copy(c->pend_tris.begin(), c->pend_tris.end(), c->tris.begin() + (ptrdiff_t)ts);
+    for (size_t j = 0; j < ld; j++) { MqLeafRec r = c->pend_leaves[j]; r.tri0 += (uint32_t)ts; c->leaves[ls + j] = r; }
+    c->mirror_pending = false;
+}
 int mq_scene_get_bvh(const mq_ctx* c, const void** nodes, uint64_t* n_nodes, const void** tris, uint64_t* n_tris) {
     if (!c) return MQ_EINVAL;
     if (!c->committed) return MQ_ESTATE;
+    materialize_mirror(c);
     if (nodes) *nodes = c->nodes.data(); if (n_nodes) *n_nodes = c->nodes.size(); if (tris) *tris = c->tris.data(); if (n_tris) *n_tris = c->tris.size();
     return MQ_OK;
 }
 int mq_scene_get_leaves(const mq_ctx* c, const void** leaves, uint64_t* n_leaves) {
     if (!c) return MQ_EINVAL;
     if (!c->committed) return MQ_ESTATE;
+    materialize_mirror(c);
     if (leaves) *leaves = c->leaves.data(); if (n_leaves) *n_leaves = c->leaves.size();
     return MQ_OK;
 }
 int mq_scene_stats(const mq_ctx* c, uint64_t* n_tris, uint64_t* n_nodes, uint64_t* bvh_bytes, float* sah_cost) {
     if (!c) return MQ_EINVAL;
+    materialize_mirror(c);
     if (n_tris) *n_tris = c->tris.size(); if (n_nodes) *n_nodes = c->nodes.size();
     if (bvh_bytes) *bvh_bytes = c->nodes.size() * sizeof(MqNode) + c->leaves.size() * sizeof(MqLeafRec); // what a traversal reads (the 48-byte triangles serve the shading)
     if (sah_cost) *sah_cost = c->sah_cost;
@@ -759,8 +774,12 @@ void flatten_slots(mq_ctx* c, bool want_static, std::vector<MqTri>& flat) {
     }
 }
 
-void shade_records(const mq_ctx* c, const MqTri* tris, size_t n, std::vector<MqShadeRec>& recs) {
-    recs.resize(n);
+void shade_records_into(const mq_ctx* c, const MqTri* tris, size_t n, MqShadeRec* recs);
+void shade_records(const mq_ctx* c, const MqTri* tris, size_t n, std::vector<MqShadeRec>& recs) { recs.resize(n); shade_records_into(c, tris, n, recs.data()); }
+void par_copy(void* dst, const void* src, size_t bytes) { // memcpy on the worker pool (one thread does not saturate the memory system)
+    mq_parallel_for(bytes, (size_t)256 << 10, [&](size_t b, size_t e) { memcpy((char*)dst + b, (const char*)src + b, e - b); });
+}
+void shade_records_into(const mq_ctx* c, const MqTri* tris, size_t n, MqShadeRec* recs) {
     const std::vector<MqTexDesc>& desc = c->texdesc;
     mq_parallel_for(n, 8192, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {
@@ -831,15 +850,19 @@ int mq_scene_commit(mq_ctx* c) {
     const bool joined = ns != 0 && nd != 0;
     const bool in_place = !static_rebuilt && c->nodes.size() >= ns && c->tris.size() >= ts && c->leaves.size() >= ls; // the static part is where it was
     if (!in_place) { c->nodes = c->s_nodes; c->tris = c->s_tris; c->leaves = c->s_leaves; }
-    c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + ld);
-    for (size_t j = 0; j < nd; j++) { MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ls; c->nodes[ns + j] = n; }
-    std::copy(d_tris.begin(), d_tris.end(), c->tris.begin() + (ptrdiff_t)ts);
-    for (size_t j = 0; j < ld; j++) { MqLeafRec r = d_leaves[j]; r.tri0 += (uint32_t)ts; c->leaves[ls + j] = r; }
+    c->mirror_pending = false;
+    auto mirror = [&]() { // the host copy with the contiguous numbering (mq_scene_get_bvh): static part, then the per-frame part
+        c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + ld);
+        for (size_t j = 0; j < nd; j++) { MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ls; c->nodes[ns + j] = n; }
+        std::copy(d_tris.begin(), d_tris.end(), c->tris.begin() + (ptrdiff_t)ts);
+        for (size_t j = 0; j < ld; j++) { MqLeafRec r = d_leaves[j]; r.tri0 += (uint32_t)ts; c->leaves[ls + j] = r; }
+    };
+    c->n_dyn_nodes = (uint32_t)nd; c->n_dyn_tris = (uint32_t)td; c->n_dyn_leaves = (uint32_t)ld;
     c->n_static_nodes = (uint32_t)ns; c->n_static_tris = (uint32_t)ts; c->n_static_leaves = (uint32_t)ls;
     c->joined = joined;
     c->sah_cost = c->s_sah + d_sah;
     c->committed = true;
-    if (c->device < 0) { c->tex_dirty = false; return MQ_OK; } // host-only context: BVH available for inspection, nothing to upload
+    if (c->device < 0) { mirror(); c->tex_dirty = false; return MQ_OK; } // host-only context: BVH available for inspection, nothing to upload
     HIPCHK(c, hipSetDevice(c->device));
     int r;
     const bool partial = in_place && !c->tex_dirty && c->dev_scene_valid && c->dev_static_nodes == ns && c->dev_static_tris == ts && c->dev_static_leaves == ls;
@@ -854,7 +877,14 @@ int mq_scene_commit(mq_ctx* c) {
         const int p = c->dyn_parity ^ 1;
         if (!c->up_stream) { // first asynchronous commit: whatever read the scene so far is unknown to the events below
             HIPCHK(c, hipDeviceSynchronize());
-            HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+            { // a priority of its own = a hardware queue of its own: streams of one priority share a small pool of queues, and copies queued behind the frame's
+              // kernels would land only when those are done -- too late for the next frame's camera rays, which run beside them and wait for the upload
+                int least = 0, greatest = 0;
+                if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+                    (void)hipGetLastError();
+                    HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+                }
+            }
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_uploaded, hipEventDisableTiming));
             for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_scene_used[k], hipEventDisableTiming));
         }
@@ -886,7 +916,7 @@ int mq_scene_commit(mq_ctx* c) {
         char* st = (char*)c->stage[p]; size_t at = 0;
         auto push = [&](void* dev, const void* src, size_t bytes) -> int { // stage, then copy on the upload stream
             if (!bytes) return MQ_OK;
-            if (src) memcpy(st + at, src, bytes);
+            if (src) par_copy(st + at, src, bytes);
             HIPCHK(c, hipMemcpyAsync(dev, st + at, bytes, hipMemcpyHostToDevice, c->up_stream));
             at += al(bytes);
             return MQ_OK;
@@ -899,9 +929,8 @@ int mq_scene_commit(mq_ctx* c) {
             MqLeafRec* sl = (MqLeafRec*)(st + at);
             for (size_t j = 0; j < ld; j++) { MqLeafRec q = d_leaves[j]; q.tri0 += (uint32_t)ot; sl[j] = q; }
             if ((r = push((MqLeafRec*)c->d_leaves.p + ol, nullptr, ld * sizeof(MqLeafRec)))) return r;
-            std::vector<MqShadeRec> recs;
-            shade_records(c, c->tris.data() + ts, td, recs);
-            if ((r = push((MqShadeRec*)c->d_shade.p + ot, recs.data(), td * sizeof(MqShadeRec)))) return r;
+            shade_records_into(c, d_tris.data(), td, (MqShadeRec*)(st + at)); // (straight into the staging memory)
+            if ((r = push((MqShadeRec*)c->d_shade.p + ot, nullptr, td * sizeof(MqShadeRec)))) return r;
         }
         for (int sl = 0; sl < MQ_MAX_GEOMETRIES; sl++) { // per-slot arrays of region p
             MqHostGeo& g = c->geo[sl];
@@ -926,8 +955,11 @@ int mq_scene_commit(mq_ctx* c) {
         c->scene.dyn_root = nd ? (uint32_t)on : MQ_NIL;
         c->dyn_parity = p;
         c->commits_dynamic++; c->commits_async++;
+        // the host mirror is brought up to date when somebody asks for it (materialize_mirror): the trees are kept as built
+        c->pend_nodes.swap(d_nodes); c->pend_tris.swap(d_tris); c->pend_leaves.swap(d_leaves); c->mirror_pending = true;
         return MQ_OK;
     }
+    mirror();
     HIPCHK(c, hipDeviceSynchronize());
     if (c->up_stream) { c->scene_used_valid[0] = c->scene_used_valid[1] = false; c->scene_used_mixed[0] = c->scene_used_mixed[1] = false; }
     if (partial && (ns == 0 || (force_sync && fits)) && c->dyn_parity == 0 && c->d_nodes.bytes >= c->nodes.size() * sizeof(MqNode) && c->d_tris.bytes >= c->tris.size() * sizeof(MqTri) && c->d_shade.bytes >= c->tris.size() * sizeof(MqShadeRec)

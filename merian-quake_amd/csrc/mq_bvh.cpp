@@ -53,7 +53,7 @@ public:
     int threads() const { return (int)workers.size() + 1; }
     void spawn(TaskGroup& g, std::function<void()> f) {
         g.pending.fetch_add(1, std::memory_order_relaxed);
-        { std::lock_guard<std::mutex> l(m); q.emplace_back(&g, std::move(f)); }
+        { std::lock_guard<std::mutex> l(m); q.emplace_back(&g, std::move(f)); queued.fetch_add(1, std::memory_order_release); }
         cv.notify_one();
     }
     void wait(TaskGroup& g) { // run queued tasks (of any group) until this group has none left
@@ -68,8 +68,9 @@ private:
     std::mutex m; std::condition_variable cv, done;
     std::deque<std::pair<TaskGroup*, std::function<void()>>> q;
     bool stop = false;
+    std::atomic<int> queued{0}; // mirrors q.size() for the workers' short spin before they sleep (a wake-up through the condition variable costs tens of microseconds, a per-frame build a few hundred)
     void run_one(std::unique_lock<std::mutex>& l) {
-        auto t = std::move(q.front()); q.pop_front();
+        auto t = std::move(q.front()); q.pop_front(); queued.fetch_sub(1, std::memory_order_relaxed);
         l.unlock();
         t.second();
         const bool last = t.first->pending.fetch_sub(1, std::memory_order_acq_rel) == 1;
@@ -81,6 +82,11 @@ private:
         for (int i = 1; i < n; i++) workers.emplace_back([this] {
             std::unique_lock<std::mutex> l(m);
             for (;;) {
+                if (q.empty() && !stop) {
+                    l.unlock();
+                    for (int i = 0; i < 4000 && queued.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
+                    l.lock();
+                }
                 cv.wait(l, [this] { return stop || !q.empty(); });
                 if (stop) return;
                 run_one(l);
