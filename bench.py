@@ -207,6 +207,19 @@ def main():
     # device).  The frame is not partitioned; the assembled image must equal the rendered one.
     selftest = world == 1 and os.environ.get("MQ_BENCH_RCCL_SELFTEST") == "1"
     exchange = world > 1 or selftest
+
+    def nccl_options():
+        # The collectives' own stream at HIGH priority = on a hardware queue of its own: streams of one priority share a small pool of queues,
+        # and an all-gather queued in line with the frame's kernels holds that queue until every peer has arrived (the same effect,
+        # measured, on the upload stream of per-frame geometry: profiles/r03_z_per_frame_geometry.txt).  MQ_BENCH_NCCL_PRIORITY=0: default streams.
+        if os.environ.get("MQ_BENCH_NCCL_PRIORITY") == "0":
+            return None
+        try:
+            opts = torch.distributed.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            return opts
+        except Exception:
+            return None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -214,13 +227,13 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=nccl_options())
         assert dist.get_world_size() == args.gpus, "the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
     elif selftest:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=torch.device("cuda", local_rank), pg_options=nccl_options())
     else:
         torch.cuda.set_device(local_rank)
     if not torch.cuda.is_available():
@@ -279,7 +292,7 @@ def main():
                 dlocal = torch.as_tensor(_DevArray(dptr, dbytes // 4), device="cuda")
                 dgathered = torch.empty(world * (dbytes // 4), dtype=torch.float32, device="cuda")
         if overlap:
-            side = torch.cuda.Stream()
+            side = torch.cuda.Stream(priority=-1)  # (staging wait + un-tiling: beside the next frame, not in line with it)
             staging = torch.empty_like(local)
             image = torch.zeros(W * H * 4, dtype=torch.float32, device="cuda")
             if vlocal is not None:
@@ -303,8 +316,8 @@ def main():
         # The halo rows of frame n are first read by the temporal pass of frame n + 1: the exchange (and the row gather of the final
         # image) runs on a side stream and its own communicator beside the MCPG pass of frame n + 1.  MQ_BENCH_SYNC_EXCHANGE=1: in line.
         if not rehearsal and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1":
-            halo_side = torch.cuda.Stream()
-            halo_group = dist.new_group(backend="nccl") if world > 1 else None
+            halo_side = torch.cuda.Stream(priority=-1)
+            halo_group = dist.new_group(backend="nccl", pg_options=nccl_options()) if world > 1 else None
         bands = mq_bands.bands_of(ctx, W, H, world)
         which = [mqhip.HALO_RESTIR_RESERVOIRS, mqhip.HALO_ACCUM, mqhip.HALO_ACCUM_HISTORY] + ([mqhip.HALO_VOLUME_ACCUM, mqhip.HALO_VOLUME_ACCUM_HISTORY] if args.volume_spp > 0 else [])
         halo_pairs = mq_bands.halo_tensors(ctx, H, which)
