@@ -1939,10 +1939,6 @@ int mq_trace_rays(mq_ctx* c, const float* org, const float* dir, uint32_t n, uin
     if (!r && hipMemcpy(prim, d_p.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
     if (!r && hipMemcpy(t, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
     if (!r && uv && hipMemcpy(uv, d_uv.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, MQ_EHIP, "copy back");
-    if (!r && c->dyn_parity) { // triangle numbers as in mq_scene_get_bvh: the per-frame triangles follow the static ones (on the device they sit in the second region)
-        const uint32_t first = c->dev_static_tris + c->dyn_cap_tris;
-        for (uint32_t i = 0; i < n; i++) if (prim[i] != MQ_NIL && prim[i] >= first) prim[i] -= c->dyn_cap_tris;
-    }
     dev_free(d_o); dev_free(d_d); dev_free(d_p); dev_free(d_t); dev_free(d_uv); dev_free(d_sp);
     return r;
 }

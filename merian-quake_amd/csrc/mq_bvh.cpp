@@ -118,6 +118,15 @@ struct Builder {
         for (;;) {
             AABB box; box.reset();
             AABB cbox; cbox.reset();
+            const bool wide = spawn_min != 0 && count >= 16384; // the top of a large tree: the passes over its triangles run on the pool too (min / max / counts: the same bins in any order)
+            if (wide) {
+                std::mutex mm;
+                mq_parallel_for(count, 4096, [&](size_t b0, size_t b1) {
+                    AABB lb, lc; lb.reset(); lc.reset();
+                    for (size_t i = first + b0; i < first + b1; i++) { lb.grow(tbox[order[i]]); lc.grow(&cent[3 * order[i]]); }
+                    std::lock_guard<std::mutex> l(mm); box.grow(lb); cbox.grow(lc);
+                });
+            } else
             for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[order[i]]); cbox.grow(&cent[3 * order[i]]); }
             nodes[id].box = box; nodes[id].ntris = count;
             if (count <= MQ_BVH_LEAF) { nodes[id].first = first; nodes[id].count = count; return; }
@@ -131,14 +140,26 @@ struct Builder {
                     use[a] = ext > 0.0f; scale[a] = use[a] ? NB / ext : 0.0f;
                     for (int b = 0; b < NB; b++) { bb[a][b].reset(); bc[a][b] = 0; }
                 }
-                for (uint32_t i = first; i < first + count; i++) {
-                    const uint32_t t = order[i];
-                    const AABB& tb = tbox[t];
-                    for (int a = 0; a < 3; a++) if (use[a]) {
-                        const int b = std::min(NB - 1, std::max(0, (int)((cent[3 * t + a] - cbox.lo[a]) * scale[a])));
-                        bb[a][b].grow(tb); bc[a][b]++;
+                auto bin_range = [&](size_t i0, size_t i1, AABB (*xb)[NB], uint32_t (*xc)[NB]) {
+                    for (size_t i = i0; i < i1; i++) {
+                        const uint32_t t = order[i];
+                        const AABB& tb = tbox[t];
+                        for (int a = 0; a < 3; a++) if (use[a]) {
+                            const int b = std::min(NB - 1, std::max(0, (int)((cent[3 * t + a] - cbox.lo[a]) * scale[a])));
+                            xb[a][b].grow(tb); xc[a][b]++;
+                        }
                     }
-                }
+                };
+                if (wide) {
+                    std::mutex mm;
+                    mq_parallel_for(count, 4096, [&](size_t b0, size_t b1) {
+                        AABB lb[3][NB]; uint32_t lc[3][NB];
+                        for (int a = 0; a < 3; a++) for (int b = 0; b < NB; b++) { lb[a][b].reset(); lc[a][b] = 0; }
+                        bin_range(first + b0, first + b1, lb, lc);
+                        std::lock_guard<std::mutex> l(mm);
+                        for (int a = 0; a < 3; a++) for (int b = 0; b < NB; b++) { bb[a][b].grow(lb[a][b]); bc[a][b] += lc[a][b]; }
+                    });
+                } else bin_range(first, (size_t)first + count, bb, bc);
                 for (int a = 0; a < 3; a++) {
                     if (!use[a]) continue;
                     float rarea[NB]; uint32_t rcount[NB];

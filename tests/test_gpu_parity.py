@@ -196,6 +196,43 @@ def test_closest_hit_matches_oracle(gpu_ctx, scene, n):
     assert np.array_equal(uv0[hit].view(np.uint32), uv1[hit].view(np.uint32))
 
 
+def test_closest_hit_with_per_frame_geometry_in_either_device_region(mqlib):
+    """Per-frame geometry is double-buffered on the device (mq_scene_commit): three commits of a changing particle cloud
+    put the per-frame tree behind the static one, into the second region, and into the first again -- closest hits
+    (slot, triangle, t, barycentrics) equal the oracle's after each, and rays do hit the particles."""
+    import mqhip
+    ctx = mqhip.Context(0)
+    ctx.header_defaults()
+    ctx.synth_scene("synth_start", 7)
+    ctx.commit()
+    rng = np.random.default_rng(3)
+    g = ctx.get_geometry(0)
+    lo, hi = g["vtx"].min(0), g["vtx"].max(0)
+    view = mqhip.View()
+    view.forward[0] = 1.0; view.right[1] = -1.0; view.up[2] = 1.0
+    for k in range(3):
+        view.origin[k] = float(0.5 * (lo[k] + hi[k]))
+    o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))
+    for f in range(4):
+        n = 400 + 300 * f
+        parts = np.zeros(n, mqhip.PARTICLE_DTYPE)
+        parts["org"] = lo + (hi - lo) * rng.random((n, 3)); parts["prev_org"] = parts["org"] - 1.0
+        parts["seed"] = rng.integers(1, 2 ** 32, n); parts["color_rgba"] = 0x00ffffff; parts["type"] = 0
+        ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, f / 60.0, (f - 1) / 60.0); ctx.dyn_end(2)
+        ctx.commit()
+        orc.mirror_scene(ctx, o); o.commit(1)
+        org, d = random_rays(ctx, 60000, rng)
+        p0, t0, uv0 = o.trace_rays(org, d)
+        p1, t1, uv1 = ctx.trace_rays(org, d)
+        assert np.array_equal(p0, p1), "commit %d: %d prim mismatches" % (f, (p0 != p1).sum())
+        assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+        hit = p0 != 0xFFFFFFFF
+        assert np.array_equal(uv0[hit].view(np.uint32), uv1[hit].view(np.uint32))
+        assert ((p0[hit] >> 28) == 2).sum() > 50, "no ray hit a particle"
+    assert ctx.commit_async_count() == 4 and ctx.commit_counts() == (1, 4)
+    ctx.close()
+
+
 def test_oracle_bvh_equals_brute_force(gpu_ctx):
     """The oracle's own BVH and its brute-force loop agree (pins the checker)."""
     ctx = gpu_ctx
