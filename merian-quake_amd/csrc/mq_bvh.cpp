@@ -49,7 +49,7 @@ struct BNode { AABB box; int left = -1, right = -1; uint32_t first = 0, count = 
 struct TaskGroup { std::atomic<int> pending{0}; };
 class TaskPool {
 public:
-    static TaskPool& get() { static TaskPool p; return p; }
+    static TaskPool& get() { static TaskPool* p = new TaskPool; return *p; } // never destroyed: its threads sleep until the process ends (no join at exit, nothing to hang in a forked child)
     int threads() const { return (int)workers.size() + 1; }
     void spawn(TaskGroup& g, std::function<void()> f) {
         g.pending.fetch_add(1, std::memory_order_relaxed);
@@ -79,7 +79,7 @@ private:
     }
     TaskPool() {
         int n = getenv("MQ_BVH_THREADS") ? atoi(getenv("MQ_BVH_THREADS")) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-        for (int i = 1; i < n; i++) workers.emplace_back([this] {
+        for (int i = 1; i < n; i++) { workers.emplace_back([this] {
             std::unique_lock<std::mutex> l(m);
             for (;;) {
                 if (q.empty() && !stop) {
@@ -91,12 +91,7 @@ private:
                 if (stop) return;
                 run_one(l);
             }
-        });
-    }
-    ~TaskPool() {
-        { std::lock_guard<std::mutex> l(m); stop = true; }
-        cv.notify_all();
-        for (auto& t : workers) t.join();
+        }); workers.back().detach(); }
     }
 };
 
