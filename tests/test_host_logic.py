@@ -357,3 +357,32 @@ def test_deep_chain_scene_needs_more_than_the_lds_stack(mq):
     depth_back, _ = deep_scene.emulate_stack_depth(nodes, [1.6 ** 80, 0, 0], [-1, 0, 0])
     assert depth_back <= 2  # looking back from the far end the first box test culls everything beyond T_MAX
     ctx.close()
+
+
+def test_builder_output_does_not_depend_on_the_worker_pool():
+    """The host's worker pool (mq_bvh.cpp: SAH subtrees, the passes over large nodes and the collapse of <= 1024-triangle
+    subtrees as tasks, spliced into the depth-first layout) must produce the arrays a single thread produces: nodes,
+    triangles and leaf records of a 640 k-triangle static scene plus a 20 k-triangle per-frame tree, hashed in a fresh
+    process per setting (the pool's size is fixed when it starts)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import mqhip\n"
+        "c = mqhip.Context(-1); c.json_defaults(); c.synth_scene('synth_sepulcher', 2); c.commit()\n"
+        "v = mqhip.View(); v.forward[0] = 1.0; v.right[1] = -1.0; v.up[2] = 1.0\n"
+        "rng = np.random.default_rng(1); n = 5000\n"
+        "p = np.zeros(n, mqhip.PARTICLE_DTYPE); p['org'] = rng.uniform(-500, 500, (n, 3)); p['prev_org'] = p['org'] - 1; p['seed'] = rng.integers(1, 2 ** 32, n); p['color_rgba'] = 0xffffff\n"
+        "c.dyn_begin(); c.dyn_add_particles(p, v, 1, 2, 0.5, 0.4); c.dyn_end(2); c.commit()\n"
+        "nodes, tris = c.get_bvh()\n"
+        "g = c.get_geometry(2)\n"
+        "print(len(nodes), len(tris), hashlib.md5(nodes.tobytes() + tris.tobytes() + c.get_leaves().tobytes() + g['vtx'].tobytes() + g['ext'].tobytes()).hexdigest())\n"
+    ) % os.path.join(ROOT, "merian-quake_amd")
+    outs = {}
+    for name, env in (("serial", {"MQ_BVH_FORK_DEPTH": "0"}), ("one thread", {"MQ_BVH_THREADS": "1"}), ("three threads", {"MQ_BVH_THREADS": "3"}), ("eight threads", {"MQ_BVH_THREADS": "8"})):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        outs[name] = r.stdout.strip().splitlines()[-1]
+    assert len(set(outs.values())) == 1, outs
+    assert int(outs["serial"].split()[1]) == 639310 + 4 * 5000  # the static triangles + four per particle
