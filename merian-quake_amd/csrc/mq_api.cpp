@@ -982,13 +982,12 @@ int mq_scene_commit(mq_ctx* c) {
     // two regions for the per-frame part (see above), each with room to grow without another full upload; the first holds the
     // part committed now, right behind the static part -- the layout of the host mirror
     const size_t cap_tris = td + 16384, cap_nodes = nd + 8192;
-    const size_t slack_tris = 2 * cap_tris - td, slack_nodes = 2 * cap_nodes - nd;
-    if ((r = dev_alloc(c, c->d_nodes, (c->nodes.size() + slack_nodes) * sizeof(MqNode)))) return r;
-    if ((r = dev_alloc(c, c->d_tris, (c->tris.size() + slack_tris) * sizeof(MqTri)))) return r;
-    if ((r = dev_alloc(c, c->d_leaves, (c->leaves.size() + slack_tris) * sizeof(MqLeafRec)))) return r; // (at most one record per triangle)
+    if ((r = dev_alloc(c, c->d_nodes, (ns + 2 * cap_nodes) * sizeof(MqNode)))) return r;
+    if ((r = dev_alloc(c, c->d_tris, (ts + 2 * cap_tris) * sizeof(MqTri)))) return r;
+    if ((r = dev_alloc(c, c->d_leaves, (ls + 2 * cap_tris) * sizeof(MqLeafRec)))) return r; // (at most one record per triangle: a region holds cap_tris records)
     if (!c->leaves.empty()) HIPCHK(c, hipMemcpy(c->d_leaves.p, c->leaves.data(), c->leaves.size() * sizeof(MqLeafRec), hipMemcpyHostToDevice));
     c->dyn_cap_nodes = (uint32_t)cap_nodes; c->dyn_cap_tris = (uint32_t)cap_tris; c->dyn_parity = 0;
-    if ((r = dev_alloc(c, c->d_shade, (c->tris.size() + slack_tris) * sizeof(MqShadeRec)))) return r;
+    if ((r = dev_alloc(c, c->d_shade, (ts + 2 * cap_tris) * sizeof(MqShadeRec)))) return r;
     if (!c->nodes.empty()) HIPCHK(c, hipMemcpy(c->d_nodes.p, c->nodes.data(), c->nodes.size() * sizeof(MqNode), hipMemcpyHostToDevice));
     if (!c->tris.empty()) HIPCHK(c, hipMemcpy(c->d_tris.p, c->tris.data(), c->tris.size() * sizeof(MqTri), hipMemcpyHostToDevice));
     if ((r = upload_slot_arrays(c, true))) return r;

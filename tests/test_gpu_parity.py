@@ -198,7 +198,7 @@ def test_closest_hit_matches_oracle(gpu_ctx, scene, n):
 
 def test_closest_hit_with_per_frame_geometry_in_either_device_region(mqlib):
     """Per-frame geometry is double-buffered on the device (mq_scene_commit): three commits of a changing particle cloud
-    put the per-frame tree behind the static one, into the second region, and into the first again -- closest hits
+    put the per-frame tree into the second region, the first, the second ... (the last two fill a region to the last triangle) -- closest hits
     (slot, triangle, t, barycentrics) equal the oracle's after each, and rays do hit the particles."""
     import mqhip
     ctx = mqhip.Context(0)
@@ -213,8 +213,8 @@ def test_closest_hit_with_per_frame_geometry_in_either_device_region(mqlib):
     for k in range(3):
         view.origin[k] = float(0.5 * (lo[k] + hi[k]))
     o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))
-    for f in range(4):
-        n = 400 + 300 * f
+    for f in range(6):
+        n = 400 + 300 * f if f < 4 else 4096  # the last two: 16 384 triangles = exactly what a region holds (the first commit sized them for 0 + 16 384), one per region
         parts = np.zeros(n, mqhip.PARTICLE_DTYPE)
         parts["org"] = lo + (hi - lo) * rng.random((n, 3)); parts["prev_org"] = parts["org"] - 1.0
         parts["seed"] = rng.integers(1, 2 ** 32, n); parts["color_rgba"] = 0x00ffffff; parts["type"] = 0
@@ -229,7 +229,7 @@ def test_closest_hit_with_per_frame_geometry_in_either_device_region(mqlib):
         hit = p0 != 0xFFFFFFFF
         assert np.array_equal(uv0[hit].view(np.uint32), uv1[hit].view(np.uint32))
         assert ((p0[hit] >> 28) == 2).sum() > 50, "no ray hit a particle"
-    assert ctx.commit_async_count() == 4 and ctx.commit_counts() == (1, 4)
+    assert ctx.commit_async_count() == 6 and ctx.commit_counts() == (1, 6)
     ctx.close()
 
 
