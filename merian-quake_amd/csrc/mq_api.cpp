@@ -126,6 +126,7 @@ struct mq_ctx {
     hipEvent_t ev_scene_used[2] = {nullptr, nullptr}; bool scene_used_valid[2] = {false, false}; // last launch that read region p
     hipStream_t scene_used_stream[2] = {nullptr, nullptr}; bool scene_used_mixed[2] = {false, false}; // (read from more than one stream: the commit falls back to a device synchronisation)
     uint32_t commits_async = 0;
+    std::vector<MqTri> flat_scratch;
     std::vector<MqNode> pend_nodes; std::vector<MqTri> pend_tris; std::vector<MqLeafRec> pend_leaves; bool mirror_pending = false; // per-frame trees of the last asynchronous commit, not yet in nodes / tris / leaves
     uint32_t n_dyn_nodes = 0, n_dyn_tris = 0, n_dyn_leaves = 0;
     // frame state
@@ -834,12 +835,13 @@ int mq_scene_commit(mq_ctx* c) {
     if (!c) return MQ_EINVAL;
     const auto t_commit = std::chrono::steady_clock::now();
     std::string err;
-    std::vector<MqTri> flat;
+    std::vector<MqTri>& flat = c->flat_scratch; // (kept from commit to commit: a per-frame commit does not zero-fill it again)
     const bool static_rebuilt = c->static_dirty;
     if (c->static_dirty) {
         flatten_slots(c, true, flat);
         if (!mq_build_cwbvh(flat, c->s_nodes, c->s_tris, c->s_leaves, &c->s_sah, err, &c->s_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
         c->static_dirty = false;
+        std::vector<MqTri>().swap(flat); // (the static triangles: not worth keeping)
     }
     std::vector<MqNode> d_nodes; std::vector<MqTri> d_tris; std::vector<MqLeafRec> d_leaves; float d_sah = 0.0f;
     flatten_slots(c, false, flat);

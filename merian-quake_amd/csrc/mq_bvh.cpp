@@ -51,6 +51,7 @@ class TaskPool {
 public:
     static TaskPool& get() { static TaskPool* p = new TaskPool; return *p; } // never destroyed: its threads sleep until the process ends (no join at exit, nothing to hang in a forked child)
     int threads() const { return (int)workers.size() + 1; }
+    struct Busy { TaskPool& p; explicit Busy(TaskPool& pool) : p(pool) { p.active.fetch_add(1); } ~Busy() { p.active.fetch_sub(1); } };
     void spawn(TaskGroup& g, std::function<void()> f) {
         g.pending.fetch_add(1, std::memory_order_relaxed);
         { std::lock_guard<std::mutex> l(m); q.emplace_back(&g, std::move(f)); queued.fetch_add(1, std::memory_order_release); }
@@ -68,6 +69,7 @@ private:
     std::mutex m; std::condition_variable cv, done;
     std::deque<std::pair<TaskGroup*, std::function<void()>>> q;
     bool stop = false;
+    std::atomic<int> active{0}; // builds / parallel loops in progress: the workers do not go to sleep between their tasks (every wake-up is a system call on the thread that spawns)
     std::atomic<int> queued{0}; // mirrors q.size() for the workers' short spin before they sleep (a wake-up through the condition variable costs tens of microseconds, a per-frame build a few hundred)
     void run_one(std::unique_lock<std::mutex>& l) {
         auto t = std::move(q.front()); q.pop_front(); queued.fetch_sub(1, std::memory_order_relaxed);
@@ -84,7 +86,7 @@ private:
             for (;;) {
                 if (q.empty() && !stop) {
                     l.unlock();
-                    for (int i = 0; i < 4000 && queued.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
+                    for (int i = 0; (i < 4000 || (active.load(std::memory_order_relaxed) > 0 && i < 2000000)) && queued.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
                     l.lock();
                 }
                 cv.wait(l, [this] { return stop || !q.empty(); });
@@ -97,14 +99,14 @@ private:
 
 struct Builder {
     const std::vector<MqTri>& in;
-    std::vector<AABB> tbox;
-    std::vector<float> cent; // 3 per tri
-    std::vector<uint32_t> order;
-    std::vector<BNode> nodes; // preallocated, 2 per triangle: a subtree over `count` triangles owns the ids [id, id + 2 * count - 1)
+    std::vector<AABB>& tbox;
+    std::vector<float>& cent; // 3 per tri
+    std::vector<uint32_t>& order;
+    std::vector<BNode>& nodes; // preallocated, 2 per triangle: a subtree over `count` triangles owns the ids [id, id + 2 * count - 1)
     TaskGroup group;
     uint32_t spawn_min = 0;   // subtrees of at least this many triangles become tasks of the pool (0: single-threaded build)
 
-    explicit Builder(const std::vector<MqTri>& t) : in(t) {}
+    Builder(const std::vector<MqTri>& t, std::vector<AABB>& tb, std::vector<float>& ce, std::vector<uint32_t>& od, std::vector<BNode>& nd) : in(t), tbox(tb), cent(ce), order(od), nodes(nd) {}
 
     // Binned SAH over the three axes, 16 bins, the three axes binned in ONE pass over the triangles.  The two halves of a split
     // touch disjoint ranges of `order` and their own node ids (known before they are built), so large halves are handed to the
@@ -124,7 +126,8 @@ struct Builder {
             } else
             for (uint32_t i = first; i < first + count; i++) { box.grow(tbox[order[i]]); cbox.grow(&cent[3 * order[i]]); }
             nodes[id].box = box; nodes[id].ntris = count;
-            if (count <= MQ_BVH_LEAF) { nodes[id].first = first; nodes[id].count = count; return; }
+            if (count <= MQ_BVH_LEAF) { nodes[id].first = first; nodes[id].count = count; nodes[id].left = nodes[id].right = -1; return; }
+            nodes[id].first = 0; nodes[id].count = 0; // (the node array is reused from build to build: every field is set)
             const int NB = 16;
             int best_axis = -1, best_split = 0; float best_cost = INFINITY;
             if (depth < 48) {
@@ -202,6 +205,7 @@ void mq_parallel_for(size_t n, size_t grain, const std::function<void(size_t, si
     static const bool serial = getenv("MQ_BVH_FORK_DEPTH") && atoi(getenv("MQ_BVH_FORK_DEPTH")) == 0;
     if (grain == 0) grain = 1;
     if (serial || n <= grain || TaskPool::get().threads() == 1) { if (n) f(0, n); return; }
+    TaskPool::Busy busy(TaskPool::get());
     TaskGroup g;
     for (size_t b = 0; b < n; b += grain) { const size_t e = std::min(n, b + grain); TaskPool::get().spawn(g, [&f, b, e] { f(b, e); }); }
     TaskPool::get().wait(g);
@@ -261,8 +265,15 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
     if (sah_cost) *sah_cost = 0.0f;
     const uint32_t n = (uint32_t)tris.size();
     if (n == 0) return true;
-    Builder B(tris);
-    B.tbox.resize(n); B.cent.resize(3 * (size_t)n); B.order.resize(n);
+    // The builder's scratch arrays live as long as the calling thread (a game commits per-frame geometry every frame: zero-filling
+    // 10 MB of scratch per build was a tenth of a 65 k-triangle commit); every element in use is written before it is read.  A build
+    // of more than a million triangles gives its scratch back.
+    TaskPool::Busy busy(TaskPool::get());
+    struct Scratch { std::vector<AABB> tbox; std::vector<float> cent; std::vector<uint32_t> order; std::vector<BNode> nodes; };
+    static thread_local Scratch scratch;
+    Builder B(tris, scratch.tbox, scratch.cent, scratch.order, scratch.nodes);
+    struct Release { Scratch& s; bool all; ~Release() { if (all) { Scratch e; std::swap(s, e); } } } release{scratch, n > 1000000u};
+    if (B.tbox.size() < n) { B.tbox.resize(n); B.cent.resize(3 * (size_t)n); B.order.resize(n); }
     float maxabs = 1.0f;
     {
         std::mutex mm; bool bad = false;
@@ -284,7 +295,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
         if (bad) { err = "non-finite vertex"; return false; }
     }
     const float pad = std::max(1e-4f, maxabs * 4.76837158203125e-07f); // 2^-21 * extent
-    B.nodes.resize(2 * (size_t)n);
+    if (B.nodes.size() < 2 * (size_t)n) B.nodes.resize(2 * (size_t)n);
     auto T0 = std::chrono::steady_clock::now();
     static const int fork_depth = getenv("MQ_BVH_FORK_DEPTH") ? atoi(getenv("MQ_BVH_FORK_DEPTH")) : 5; // 0: single-threaded build
     B.spawn_min = (fork_depth > 0 && n >= 2048 && TaskPool::get().threads() > 1) ? std::max(512u, n / 256u) : 0u;
@@ -326,7 +337,7 @@ bool mq_build_cwbvh(const std::vector<MqTri>& tris, std::vector<MqNode>& out_nod
     const uint32_t COLLAPSE_PART = 1024;
     std::vector<int> part_root;            // binary nodes whose subtrees are collapsed on their own
     std::vector<Collapsed> parts;
-    std::vector<int> part_of(dfs_order && n >= 4 * COLLAPSE_PART ? B.nodes.size() : 0, -1); // (the splice relies on the depth-first order)
+    std::vector<int> part_of(dfs_order && n >= 4 * COLLAPSE_PART ? 2 * (size_t)n : 0, -1); // (the splice relies on the depth-first order)
     auto collapse = [&](int root_bnode, uint32_t depth0, Collapsed& out, bool splice) {
     std::vector<MqNode>& out_nodes = out.nodes; std::vector<MqLeafRec>& out_leaves = out.leaves; std::vector<MqTri>& out_tris = out.tris;
     double& sah = out.sah; uint32_t& max_depth = out.max_depth;
