@@ -227,7 +227,10 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=nccl_options())
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=nccl_options())
+            except TypeError:  # (a torch without that keyword: default streams)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus, "the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
     elif selftest:
         import torch.distributed as dist
@@ -317,7 +320,10 @@ def main():
         # image) runs on a side stream and its own communicator beside the MCPG pass of frame n + 1.  MQ_BENCH_SYNC_EXCHANGE=1: in line.
         if not rehearsal and os.environ.get("MQ_BENCH_SYNC_EXCHANGE") != "1":
             halo_side = torch.cuda.Stream(priority=-1)
-            halo_group = dist.new_group(backend="nccl", pg_options=nccl_options()) if world > 1 else None
+            try:
+                halo_group = dist.new_group(backend="nccl", pg_options=nccl_options()) if world > 1 else None
+            except TypeError:
+                halo_group = dist.new_group(backend="nccl") if world > 1 else None
         bands = mq_bands.bands_of(ctx, W, H, world)
         which = [mqhip.HALO_RESTIR_RESERVOIRS, mqhip.HALO_ACCUM, mqhip.HALO_ACCUM_HISTORY] + ([mqhip.HALO_VOLUME_ACCUM, mqhip.HALO_VOLUME_ACCUM_HISTORY] if args.volume_spp > 0 else [])
         halo_pairs = mq_bands.halo_tensors(ctx, H, which)
