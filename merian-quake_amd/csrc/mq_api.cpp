@@ -23,6 +23,7 @@
 #include <dlfcn.h>
 
 #include "mq_host.h"
+#include "mq_devbvh.h"
 #include "mq_device.h" // host-callable grid_width(): the per-level tables must carry the kernels' own float results
 
 // launchers implemented in mq_kernels.hip
@@ -127,6 +128,12 @@ struct mq_ctx {
     hipStream_t scene_used_stream[2] = {nullptr, nullptr}; bool scene_used_mixed[2] = {false, false}; // (read from more than one stream: the commit falls back to a device synchronisation)
     uint32_t commits_async = 0;
     std::vector<MqTri> flat_scratch;
+    // the tree of the per-frame geometry built on the device (property "per-frame BVH"; mq_devbvh.hip)
+    DevBuf d_db_scratch; uint32_t db_cap = 0;  // the builder's scratch for up to db_cap triangles
+    uint32_t* db_ctr_host[2] = {nullptr, nullptr}; // pinned copies of the builder's counters per region (node count, flags), read after the fact
+    bool db_ctr_pending[2] = {false, false};
+    bool mirror_from_device = false; uint32_t db_tris[2] = {0, 0};
+    uint32_t commits_device = 0;
     std::vector<MqNode> pend_nodes; std::vector<MqTri> pend_tris; std::vector<MqLeafRec> pend_leaves; bool mirror_pending = false; // per-frame trees of the last asynchronous commit, not yet in nodes / tris / leaves
     uint32_t n_dyn_nodes = 0, n_dyn_tris = 0, n_dyn_leaves = 0;
     // frame state
@@ -328,6 +335,7 @@ const PropDesc k_props[] = {
     {"debug: log learning writes", PT_BOOL, POFF(log_learning), false, {}},
     {"debug: LC lock statistics", PT_BOOL, POFF(lc_lock_statistics), false, {}},
     {"LC try-lock", PT_BOOL, POFF(lc_try_lock), false, {}},
+    {"per-frame BVH", PT_OPTION, POFF(dyn_bvh), false, {"host", "device", "auto"}},
     {"debug: sequential update pass", PT_BOOL, POFF(sequential_update_pass), false, {}},
     // scheduling of this build (no reference counterpart): number of concurrent sub-pipelines a frame is cut into
     {"pipelines", PT_INT, POFF(pipelines), true, {}},
@@ -576,7 +584,8 @@ void mq_destroy(mq_ctx* c) {
         if (c->ev_bounced) (void)hipEventDestroy(c->ev_bounced);
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         if (c->ev_uploaded) (void)hipEventDestroy(c->ev_uploaded);
-        for (int k = 0; k < 2; k++) { if (c->ev_scene_used[k]) (void)hipEventDestroy(c->ev_scene_used[k]); if (c->stage[k]) (void)hipHostFree(c->stage[k]); }
+        for (int k = 0; k < 2; k++) { if (c->ev_scene_used[k]) (void)hipEventDestroy(c->ev_scene_used[k]); if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->db_ctr_host[k]) (void)hipHostFree(c->db_ctr_host[k]); }
+        dev_free(c->d_db_scratch);
         for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) if (e4) (void)hipEventDestroy(e4);
         for (int k = 0; k < mq_ctx::MAX_SUBS - 1; k++) { if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); if (c->side[k]) (void)hipStreamDestroy(c->side[k]); }
     }
@@ -720,6 +729,21 @@ int mq_scene_get_texture(const mq_ctx* c, uint32_t texnum, uint32_t* w, uint32_t
 static void materialize_mirror(const mq_ctx* cc) { // (the inspection calls take a const context; the mirror is a cache)
     mq_ctx* c = const_cast<mq_ctx*>(cc);
     if (!c->mirror_pending) return;
+    if (c->mirror_from_device) { // a tree built on the device: read its region back (inspection only; waits for the device)
+        const int p = c->dyn_parity;
+        const size_t ns = c->n_static_nodes, ts = c->n_static_tris, ls = c->n_static_leaves, td = c->db_tris[p];
+        const size_t on = ns + (size_t)p * c->dyn_cap_nodes, ot = ts + (size_t)p * c->dyn_cap_tris, ol = ls + (size_t)p * c->dyn_cap_tris;
+        (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
+        const size_t nd = td ? c->db_ctr_host[p][MQ_DB_NODES] : 0;
+        c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + td);
+        if (nd) (void)hipMemcpy(c->nodes.data() + ns, (const MqNode*)c->d_nodes.p + on, nd * sizeof(MqNode), hipMemcpyDeviceToHost);
+        if (td) (void)hipMemcpy(c->tris.data() + ts, (const MqTri*)c->d_tris.p + ot, td * sizeof(MqTri), hipMemcpyDeviceToHost);
+        if (td) (void)hipMemcpy(c->leaves.data() + ls, (const MqLeafRec*)c->d_leaves.p + ol, td * sizeof(MqLeafRec), hipMemcpyDeviceToHost);
+        for (size_t j = 0; j < nd; j++) { MqNode& n = c->nodes[ns + j]; n.child_base -= (uint32_t)(on - ns); n.tri_base -= (uint32_t)(ol - ls); } // the contiguous numbering
+        for (size_t j = 0; j < td; j++) c->leaves[ls + j].tri0 -= (uint32_t)(ot - ts);
+        c->mirror_pending = false;
+        return;
+    }
     const size_t ns = c->n_static_nodes, ts = c->n_static_tris, ls = c->n_static_leaves, nd = c->pend_nodes.size(), td = c->pend_tris.size(), ld = c->pend_leaves.size();
     c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + ld);
     for (size_t j = 0; j < nd; j++) { MqNode n = c->pend_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ls; c->nodes[ns + j] = n; }
@@ -829,6 +853,120 @@ int scene_used(mq_ctx* c, hipStream_t s) {
     c->scene_used_valid[p] = true; c->scene_used_stream[p] = s;
     return MQ_OK;
 }
+
+// The streams and events of the asynchronous commits (created by the first of them).
+int ensure_upload_stream(mq_ctx* c) {
+    if (c->up_stream) return MQ_OK;
+    HIPCHK(c, hipDeviceSynchronize()); // whatever read the scene so far is unknown to the events below
+    { // a priority of its own = a hardware queue of its own: streams of one priority share a small pool of queues, and copies queued behind the frame's
+      // kernels would land only when those are done -- too late for the next frame's camera rays, which run beside them and wait for the upload
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        }
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_uploaded, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_scene_used[k], hipEventDisableTiming));
+    return MQ_OK;
+}
+
+// A commit of per-frame geometry whose tree is built ON THE DEVICE (property "per-frame BVH"): the flattened triangles and the
+// per-slot arrays go up through the staging memory of region p, mq_devbvh.hip builds nodes, leaf records, triangles and shading
+// records in place on the upload stream.  Same regions, same events as the host-built asynchronous commit.
+int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
+    const size_t ns = c->s_nodes.size(), ts = c->s_tris.size(), ls = c->s_leaves.size(), td = flat.size();
+    int r;
+    if ((r = ensure_upload_stream(c))) return r;
+    const int p = c->dyn_parity ^ 1;
+    if (c->scene_used_mixed[p]) { HIPCHK(c, hipDeviceSynchronize()); }
+    else if (c->scene_used_valid[p]) HIPCHK(c, hipEventSynchronize(c->ev_scene_used[p]));
+    c->scene_used_valid[p] = false; c->scene_used_mixed[p] = false;
+    HIPCHK(c, hipStreamSynchronize(c->up_stream));
+    for (int k = 0; k < 2; k++) if (c->db_ctr_pending[k]) { // what the last builds reported
+        c->db_ctr_pending[k] = false;
+        if (c->db_ctr_host[k][MQ_DB_ERR]) return fail(c, MQ_EHIP, "the device builder of the per-frame tree flagged an overflow (flags " + std::to_string(c->db_ctr_host[k][MQ_DB_ERR]) + ")");
+    }
+    const size_t on = ns + (size_t)p * c->dyn_cap_nodes, ot = ts + (size_t)p * c->dyn_cap_tris, ol = ls + (size_t)p * c->dyn_cap_tris;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // scratch of the builder: grown in steps (a growth waits for the device)
+    if (c->db_cap < td) {
+        const uint32_t cap = (uint32_t)std::max<size_t>(td + td / 2, 16384);
+        const size_t bytes = al((size_t)cap * sizeof(MqTri)) + 4 * al((size_t)cap * 4) + al((size_t)cap * 2 * 4) + al((size_t)cap * 8) + al((size_t)cap * 2 * 24) + al((size_t)cap * 4)
+                           + 2 * al((size_t)cap * 8) + al(MQ_DB_WORDS * 4) + al(mq_device_bvh_sort_bytes(cap));
+        if ((r = dev_alloc(c, c->d_db_scratch, bytes))) return r;
+        c->db_cap = cap;
+    }
+    for (int k = 0; k < 2; k++) if (!c->db_ctr_host[k]) HIPCHK(c, hipHostMalloc((void**)&c->db_ctr_host[k], MQ_DB_WORDS * 4, hipHostMallocDefault));
+    size_t need = al(td * sizeof(MqTri));
+    for (int sl = 0; sl < MQ_MAX_GEOMETRIES; sl++) {
+        const MqHostGeo& g = c->geo[sl];
+        if ((g.flags & MQ_GEO_STATIC) || !g.n_tri()) continue;
+        need += al(g.ext.size() * sizeof(mq_ext)) + al(g.idx.size() * 4) + al(g.prev_vtx.size() * 4);
+    }
+    if (c->stage_bytes[p] < need) {
+        if (c->stage[p]) HIPCHK(c, hipHostFree(c->stage[p]));
+        c->stage[p] = nullptr; c->stage_bytes[p] = 0;
+        HIPCHK(c, hipHostMalloc(&c->stage[p], need + need / 2 + 65536, hipHostMallocDefault));
+        c->stage_bytes[p] = need + need / 2 + 65536;
+    }
+    char* st = (char*)c->stage[p]; size_t at = 0;
+    auto push = [&](void* dev, const void* src, size_t bytes) -> int {
+        if (!bytes) return MQ_OK;
+        par_copy(st + at, src, bytes);
+        HIPCHK(c, hipMemcpyAsync(dev, st + at, bytes, hipMemcpyHostToDevice, c->up_stream));
+        at += al(bytes);
+        return MQ_OK;
+    };
+    // carve the scratch
+    MqDevBvh A; memset(&A, 0, sizeof A);
+    { char* q = (char*)c->d_db_scratch.p; const size_t cap = c->db_cap;
+      auto take = [&](size_t bytes) { char* x = q; q += al(bytes); return x; };
+      A.in = (const MqTri*)take(cap * sizeof(MqTri));
+      A.keys0 = (uint32_t*)take(cap * 4); A.keys1 = (uint32_t*)take(cap * 4); A.vals0 = (uint32_t*)take(cap * 4); A.vals1 = (uint32_t*)take(cap * 4);
+      A.parent = (int*)take(cap * 2 * 4); A.child = (int2*)take(cap * 8); A.box = (float*)take(cap * 2 * 24); A.flag = (uint32_t*)take(cap * 4);
+      A.queue0 = (uint2*)take(cap * 8); A.queue1 = (uint2*)take(cap * 8); A.ctr = (uint32_t*)take(MQ_DB_WORDS * 4); }
+    void* sort_tmp = (char*)A.ctr + al(MQ_DB_WORDS * 4);
+    const size_t sort_bytes = mq_device_bvh_sort_bytes(c->db_cap);
+    if ((r = push((void*)A.in, flat.data(), td * sizeof(MqTri)))) return r;
+    for (int sl = 0; sl < MQ_MAX_GEOMETRIES; sl++) { // per-slot arrays of region p (the builder reads the extra data for the shading records)
+        MqHostGeo& g = c->geo[sl];
+        if (g.flags & MQ_GEO_STATIC) continue;
+        c->scene.geo[sl].ext = nullptr; c->scene.geo[sl].idx = nullptr; c->scene.geo[sl].prev_vtx = nullptr;
+        if (!g.n_tri()) continue;
+        DevBuf& be = p ? c->d_ext_b[sl] : c->d_ext[sl]; DevBuf& bi = p ? c->d_idx_b[sl] : c->d_idx[sl]; DevBuf& bp = p ? c->d_prev_b[sl] : c->d_prev[sl];
+        auto room = [&](DevBuf& b, size_t bytes) -> int { return (!b.p || b.bytes < bytes) ? dev_alloc(c, b, bytes + bytes / 2 + 4096) : MQ_OK; };
+        if ((r = room(be, g.ext.size() * sizeof(mq_ext)))) return r;
+        if ((r = push(be.p, g.ext.data(), g.ext.size() * sizeof(mq_ext)))) return r;
+        c->scene.geo[sl].ext = (const mq_ext*)be.p;
+        if (g.dynamic) {
+            if ((r = room(bi, g.idx.size() * 4)) || (r = room(bp, g.prev_vtx.size() * 4))) return r;
+            if ((r = push(bi.p, g.idx.data(), g.idx.size() * 4)) || (r = push(bp.p, g.prev_vtx.data(), g.prev_vtx.size() * 4))) return r;
+            c->scene.geo[sl].idx = (const uint32_t*)bi.p; c->scene.geo[sl].prev_vtx = (const float*)bp.p;
+        }
+    }
+    A.n = (uint32_t)td;
+    A.nodes = (MqNode*)c->d_nodes.p; A.leaves = (MqLeafRec*)c->d_leaves.p; A.tris = (MqTri*)c->d_tris.p; A.shade = (MqShadeRec*)c->d_shade.p;
+    A.node_base = (uint32_t)on; A.leaf_base = (uint32_t)ol; A.tri_base = (uint32_t)ot; A.node_cap = c->dyn_cap_nodes;
+    A.sc = c->scene; // (with the per-slot pointers of region p set above)
+    if (td) {
+        int e = mq_launch_device_bvh(A, sort_tmp, sort_bytes, c->up_stream);
+        if (e) return fail(c, MQ_EHIP, std::string("device BVH build: ") + hipGetErrorString((hipError_t)e));
+        HIPCHK(c, hipMemcpyAsync(c->db_ctr_host[p], A.ctr, MQ_DB_WORDS * 4, hipMemcpyDeviceToHost, c->up_stream));
+        c->db_ctr_pending[p] = true;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_uploaded, c->up_stream));
+    c->uploaded_valid = true;
+    c->scene.n_nodes = (uint32_t)(on + (td ? 1 : 0)); c->scene.n_tris = (uint32_t)(ot + td);
+    c->scene.dyn_root = td ? (uint32_t)on : MQ_NIL;
+    c->dyn_parity = p;
+    c->n_static_nodes = (uint32_t)ns; c->n_static_tris = (uint32_t)ts; c->n_static_leaves = (uint32_t)ls;
+    c->joined = td != 0; c->sah_cost = c->s_sah; c->d_depth = td ? MQ_DB_LEVELS : 0; c->committed = true;
+    c->db_tris[p] = (uint32_t)td;
+    c->commits_dynamic++; c->commits_async++; c->commits_device++;
+    c->mirror_pending = true; c->mirror_from_device = true;
+    return MQ_OK;
+}
 } // namespace
 
 int mq_scene_commit(mq_ctx* c) {
@@ -845,6 +983,18 @@ int mq_scene_commit(mq_ctx* c) {
     }
     std::vector<MqNode> d_nodes; std::vector<MqTri> d_tris; std::vector<MqLeafRec> d_leaves; float d_sah = 0.0f;
     flatten_slots(c, false, flat);
+    { // the per-frame tree built on the device (property "per-frame BVH"): only for commits that can take the asynchronous path (see below)
+        static const bool force_sync0 = getenv("MQ_DEBUG_COMMIT_SYNC") != nullptr;
+        static const size_t auto_tris = getenv("MQ_DEVBVH_AUTO_TRIS") ? (size_t)atol(getenv("MQ_DEVBVH_AUTO_TRIS")) : 4096;
+        const size_t ns0 = c->s_nodes.size(), ts0 = c->s_tris.size(), ls0 = c->s_leaves.size(), td0 = flat.size();
+        const bool partial0 = !static_rebuilt && c->nodes.size() >= ns0 && c->tris.size() >= ts0 && c->leaves.size() >= ls0 && !c->tex_dirty && c->dev_scene_valid
+            && c->dev_static_nodes == ns0 && c->dev_static_tris == ts0 && c->dev_static_leaves == ls0;
+        const bool wanted = c->props.dyn_bvh == 1 || (c->props.dyn_bvh == 2 && td0 >= auto_tris);
+        if (c->device >= 0 && wanted && partial0 && ns0 != 0 && !force_sync0 && c->dyn_cap_tris != 0 && td0 <= c->dyn_cap_tris && td0 <= c->dyn_cap_nodes) {
+            HIPCHK(c, hipSetDevice(c->device));
+            return commit_per_frame_on_device(c, flat);
+        }
+    }
     if (!mq_build_cwbvh(flat, d_nodes, d_tris, d_leaves, &d_sah, err, &c->d_depth)) return fail(c, MQ_EINVAL, "bvh build: " + err);
     const size_t ns = c->s_nodes.size(), nd = d_nodes.size(), ts = c->s_tris.size(), td = d_tris.size(), ls = c->s_leaves.size(), ld = d_leaves.size();
     // layout: the static tree as built, then the per-frame tree (indices offset); the traversal starts at node 0 and
@@ -852,7 +1002,7 @@ int mq_scene_commit(mq_ctx* c) {
     const bool joined = ns != 0 && nd != 0;
     const bool in_place = !static_rebuilt && c->nodes.size() >= ns && c->tris.size() >= ts && c->leaves.size() >= ls; // the static part is where it was
     if (!in_place) { c->nodes = c->s_nodes; c->tris = c->s_tris; c->leaves = c->s_leaves; }
-    c->mirror_pending = false;
+    c->mirror_pending = false; c->mirror_from_device = false;
     auto mirror = [&]() { // the host copy with the contiguous numbering (mq_scene_get_bvh): static part, then the per-frame part
         c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + ld);
         for (size_t j = 0; j < nd; j++) { MqNode n = d_nodes[j]; n.child_base += (uint32_t)ns; n.tri_base += (uint32_t)ls; c->nodes[ns + j] = n; }
@@ -877,19 +1027,7 @@ int mq_scene_commit(mq_ctx* c) {
     const bool fits = c->dyn_cap_tris != 0 && nd <= c->dyn_cap_nodes && td <= c->dyn_cap_tris && ld <= c->dyn_cap_tris;
     if (partial && ns != 0 && fits && !force_sync) {
         const int p = c->dyn_parity ^ 1;
-        if (!c->up_stream) { // first asynchronous commit: whatever read the scene so far is unknown to the events below
-            HIPCHK(c, hipDeviceSynchronize());
-            { // a priority of its own = a hardware queue of its own: streams of one priority share a small pool of queues, and copies queued behind the frame's
-              // kernels would land only when those are done -- too late for the next frame's camera rays, which run beside them and wait for the upload
-                int least = 0, greatest = 0;
-                if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&c->up_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
-                    (void)hipGetLastError();
-                    HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
-                }
-            }
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_uploaded, hipEventDisableTiming));
-            for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_scene_used[k], hipEventDisableTiming));
-        }
+        if ((r = ensure_upload_stream(c))) return r;
         static const bool times = getenv("MQ_DEBUG_COMMIT_TIMES") != nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -983,7 +1121,7 @@ int mq_scene_commit(mq_ctx* c) {
     memset(&c->scene, 0, sizeof c->scene); c->scene.dyn_root = MQ_NIL;
     // two regions for the per-frame part (see above), each with room to grow without another full upload; the first holds the
     // part committed now, right behind the static part -- the layout of the host mirror
-    const size_t cap_tris = td + 16384, cap_nodes = nd + 8192;
+    const size_t cap_tris = td + 16384, cap_nodes = std::max(nd + 8192, c->props.dyn_bvh ? cap_tris : (size_t)0); // (a device-built tree may have as many nodes as triangles)
     if ((r = dev_alloc(c, c->d_nodes, (ns + 2 * cap_nodes) * sizeof(MqNode)))) return r;
     if ((r = dev_alloc(c, c->d_tris, (ts + 2 * cap_tris) * sizeof(MqTri)))) return r;
     if ((r = dev_alloc(c, c->d_leaves, (ls + 2 * cap_tris) * sizeof(MqLeafRec)))) return r; // (at most one record per triangle: a region holds cap_tris records)
@@ -1071,6 +1209,12 @@ int mq_scene_commit_counts(const mq_ctx* c, uint32_t* full, uint32_t* per_frame)
 int mq_scene_commit_async_count(const mq_ctx* c, uint32_t* n) {
     if (!c || !n) return MQ_EINVAL;
     *n = c->commits_async;
+    return MQ_OK;
+}
+
+int mq_scene_commit_device_count(const mq_ctx* c, uint32_t* n) {
+    if (!c || !n) return MQ_EINVAL;
+    *n = c->commits_device;
     return MQ_OK;
 }
 

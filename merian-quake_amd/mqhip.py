@@ -138,6 +138,7 @@ def load_library(path=None):
         "mq_scene_layout": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "mq_scene_commit_counts": (i32, [P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "mq_scene_commit_async_count": (i32, [P, C.POINTER(C.c_uint32)]),
+        "mq_scene_commit_device_count": (i32, [P, C.POINTER(C.c_uint32)]),
         "mq_scene_get_leaves": (i32, [P, C.POINTER(vp), C.POINTER(C.c_uint64)]),
         "mq_scene_stats": (i32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), f32p]),
         "mq_describe": (i32, [P, u32, u32, C.POINTER(IoDesc)]),
@@ -280,6 +281,11 @@ class Context:
     def commit_async_count(self):
         a = C.c_uint32()
         self._chk(self.lib.mq_scene_commit_async_count(self.h, C.byref(a)))
+        return a.value
+
+    def commit_device_count(self):
+        a = C.c_uint32()
+        self._chk(self.lib.mq_scene_commit_device_count(self.h, C.byref(a)))
         return a.value
 
     def set_constants(self, sun_color, sun_direction, fov=90.0, fov_tan_alpha_half=1.0, volume_max_t=1000.0):

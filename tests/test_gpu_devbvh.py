@@ -1,0 +1,169 @@
+"""The tree of the per-frame geometry built ON THE DEVICE (property "per-frame BVH": "device"; merian-quake_amd/csrc/mq_devbvh.hip:
+Morton codes, radix sort, Karras' hierarchy, bottom-up fit, level-by-level collapse into the host builder's 80-byte nodes and
+64-byte leaf records).  The reference leaves this build to the Vulkan driver (quake_node.cpp:896-983 + the graph's builder node).
+Order of the checks: the tree is read back and its invariants are verified on the HOST (tests/test_host_logic._walk_bvh) before
+any ray is traced through it; then closest hits against the oracle; then whole frames against a context whose trees the host builds --
+a closest-hit query does not depend on the tree it walks (ties go to the smaller key), so everything must be bit-identical."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402
+from test_host_logic import _walk_bvh  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SMALL = {"adaptive grid buf size": 1 << 18, "static grid buf size": 1 << 14, "LC buf size": 1 << 16}
+
+
+def _ctx(mode, scene="synth_start"):
+    import mqhip
+    c = mqhip.Context(0)
+    c.header_defaults()
+    c.synth_scene(scene, 4)
+    for k, v in {"randomize seed": 0, "seed": 0x5EED, **SMALL, "reference mode": 1, "spp": 1, "max path length": 3, "per-frame BVH": mode}.items():
+        c.set_property(k, v)
+    c.commit()
+    return c
+
+
+def _view(ctx):
+    import mqhip
+    u0 = ctx.synth_camera(0)
+    v = mqhip.View()
+    for k in range(3):
+        v.origin[k] = u0.cam_x[k]; v.forward[k] = u0.cam_w[k]; v.up[k] = u0.cam_u[k]
+    r = np.cross([u0.cam_w[0], u0.cam_w[1], u0.cam_w[2]], [u0.cam_u[0], u0.cam_u[1], u0.cam_u[2]])
+    for k in range(3):
+        v.right[k] = float(r[k])
+    return u0, v
+
+
+def _cloud(rng, n, centre, spread):
+    import mqhip
+    p = np.zeros(n, mqhip.PARTICLE_DTYPE)
+    p["org"] = centre + rng.uniform(-spread, spread, (n, 3)); p["prev_org"] = p["org"] - rng.uniform(-2, 2, (n, 3))
+    p["seed"] = rng.integers(1, 2 ** 32, n); p["color_rgba"] = rng.choice([0x0000003c, 0x00ffffff, 0x0040a0ff], n); p["type"] = rng.choice([0, 3, 5], n)
+    return p
+
+
+def _check_tree(ctx, n_tris):
+    """host-side invariants of the per-frame tree as the device left it; returns (nodes, leaf records) of that tree"""
+    nodes, tris = ctx.get_bvh()
+    leaves = ctx.get_leaves()
+    n_s, t_s = ctx.scene_layout()
+    assert len(tris) - t_s == n_tris and len(nodes) > n_s
+    seen_nodes, seen_tris = _walk_bvh(nodes, tris, n_s, leaves)
+    assert seen_tris == set(range(t_s, t_s + n_tris)), "every per-frame triangle exactly once"
+    assert seen_nodes == set(range(n_s, len(nodes))), "every node the builder allocated hangs in the tree"
+    assert len(np.unique(tris["key"][t_s:])) == n_tris
+    return len(nodes) - n_s
+
+
+@pytest.mark.parametrize("n_particles", [1, 2, 7, 300, 5000])
+def test_device_built_tree_is_well_formed_and_hits_like_the_oracle(mqlib, n_particles):
+    ctx = _ctx("device")
+    u0, view = _view(ctx)
+    rng = np.random.default_rng(n_particles)
+    g = ctx.get_geometry(0)
+    lo, hi = g["vtx"].min(0), g["vtx"].max(0)
+    o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))
+    # (a cloud beyond the 16 384 triangles the regions were sized for at the first commit takes the host builder's full path once: the regions grow with it)
+    parts = _cloud(rng, n_particles + 3, 0.5 * (lo + hi), 0.45 * (hi - lo))
+    ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, 0.0, 0.0); ctx.dyn_end(2)
+    ctx.commit()
+    before = ctx.commit_device_count()
+    assert before == (1 if 4 * (n_particles + 3) <= 16384 else 0)
+    for f in range(3):  # both regions in turn
+        n = n_particles + f
+        parts = _cloud(rng, n, 0.5 * (lo + hi), 0.45 * (hi - lo))
+        ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, f / 60.0, (f - 1) / 60.0); ctx.dyn_end(2)
+        ctx.commit()
+        assert ctx.commit_device_count() == before + f + 1
+        n_nodes = _check_tree(ctx, 4 * n)          # BEFORE anything walks it on the device
+        assert n_nodes <= max(1, 4 * n)
+        orc.mirror_scene(ctx, o); o.commit(1)
+        org = (lo + (hi - lo) * rng.random((40000, 3))).astype(np.float32)
+        d = rng.normal(size=(40000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        p0, t0, uv0 = o.trace_rays(org, d)
+        p1, t1, uv1 = ctx.trace_rays(org, d)
+        assert np.array_equal(p0, p1), "commit %d: %d prim mismatches" % (f, (p0 != p1).sum())
+        assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+        hit = p0 != 0xFFFFFFFF
+        assert np.array_equal(uv0[hit].view(np.uint32), uv1[hit].view(np.uint32))
+        if n >= 300:
+            assert ((p0[hit] >> 28) == 2).sum() > 20, "no ray hit a particle"
+    ctx.close()
+
+
+def test_device_built_tree_of_coincident_and_degenerate_triangles(mqlib):
+    """Equal Morton codes (500 copies of one triangle, told apart by their position in the sorted order), zero-area triangles and
+    a far outlier that stretches the code grid: still a well-formed tree, still the oracle's hits."""
+    import mqhip
+    ctx = _ctx("device")
+    g = ctx.get_geometry(0)
+    lo, hi = g["vtx"].min(0), g["vtx"].max(0)
+    c = (0.5 * (lo + hi)).astype(np.float32)
+    tri = np.array([c, c + [8, 0, 0], c + [0, 8, 3]], np.float32)
+    vtx = [tri] * 500 + [np.array([c + [20, 0, 0]] * 3, np.float32)] * 10 + [tri + np.float32(30.0), np.array([hi + 1000, hi + [1001, 1000, 1000], hi + [1000, 1001, 1000]], np.float32)]
+    vtx = np.concatenate(vtx).astype(np.float32)
+    n = len(vtx) // 3
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    ext = np.zeros(n, mqhip.EXT_DTYPE); ext["texnum_alpha"] = 1 | (15 << 12)
+    rng = np.random.default_rng(2)
+    o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))
+    ctx.set_geometry(3, vtx, vtx, idx, ext, mqhip.MQ_GEO_OPAQUE)  # slot 3, not static: per-frame geometry
+    ctx.commit()
+    assert ctx.commit_device_count() == 1
+    _check_tree(ctx, n)
+    orc.mirror_scene(ctx, o); o.commit(1)
+    org = (c + rng.uniform(-40, 40, (30000, 3))).astype(np.float32)
+    d = rng.normal(size=(30000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    p0, t0, _ = o.trace_rays(org, d)
+    p1, t1, _ = ctx.trace_rays(org, d)
+    assert np.array_equal(p0, p1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    assert ((p0 >> 28) == 3).sum() > 100
+    for k in (1, 2):  # the smallest trees: one triangle (the root's only child is a leaf), two
+        ctx.set_geometry(3, vtx[:3 * k], vtx[:3 * k], idx[:k], ext[:k], mqhip.MQ_GEO_OPAQUE)
+        ctx.commit()
+        assert _check_tree(ctx, k) == 1
+        orc.mirror_scene(ctx, o); o.commit(1)
+        p0, t0, _ = o.trace_rays(org, d)
+        p1, t1, _ = ctx.trace_rays(org, d)
+        assert np.array_equal(p0, p1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32)) and ((p0 >> 28) == 3).sum() > 10
+    assert ctx.commit_device_count() == 3
+    ctx.close()
+
+
+def test_frames_do_not_depend_on_who_builds_the_per_frame_tree(mqlib):
+    """Eight frames, each with its own particle cloud (300 .. 1500 particles), issued back to back: "per-frame BVH" = device against host --
+    every node output of the last frame and the image accumulated over all of them bit-identical; "auto" takes the device from 4096
+    triangles on."""
+    import mqhip
+    outs = {}
+    for mode in ("host", "device", "auto"):
+        ctx = _ctx(mode)
+        ctx.set_property("accum: alpha", 0.9)
+        ctx.connect(480, 300)
+        u0, view = _view(ctx)
+        eye = np.array([u0.cam_x[0], u0.cam_x[1], u0.cam_x[2]]); fwd = np.array([u0.cam_w[0], u0.cam_w[1], u0.cam_w[2]])
+        rng = np.random.default_rng(77)
+        for f in range(8):
+            parts = _cloud(rng, 300 + 400 * (f % 4), eye + fwd * 40.0, 30.0)
+            ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, f / 60.0, (f - 1) / 60.0); ctx.dyn_end(2)
+            ctx.commit()
+            ctx.process(u0); ctx.post_process()
+        names = ("OUT_IRRADIANCE", "OUT_GB_ALBEDO", "OUT_GB_IRRADIANCE", "OUT_GB_MV", "OUT_GBUFFER", "OUT_HITS", "OUT_ACCUM")
+        outs[mode] = {n: ctx.read_output(getattr(mqhip, n)).copy() for n in names}
+        outs[mode]["counts"] = (ctx.commit_device_count(), ctx.commit_async_count(), ctx.counters()["queue_overflow"])
+        ctx.close()
+    assert outs["host"]["counts"] == (0, 8, 0) and outs["device"]["counts"] == (8, 8, 0) and outs["auto"]["counts"] == (4, 8, 0), [outs[m]["counts"] for m in outs]
+    for mode in ("device", "auto"):
+        for n in outs["host"]:
+            if n != "counts":
+                assert np.array_equal(outs["host"][n].view(np.uint8), outs[mode][n].view(np.uint8)), (mode, n)
+    assert outs["host"]["OUT_IRRADIANCE"].view(np.float32).sum() > 0
