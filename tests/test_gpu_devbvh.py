@@ -116,21 +116,26 @@ def test_device_built_tree_of_coincident_and_degenerate_triangles(mqlib):
     ext = np.zeros(n, mqhip.EXT_DTYPE); ext["texnum_alpha"] = 1 | (15 << 12)
     rng = np.random.default_rng(2)
     o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))
+    own = len(ctx.get_bvh()[1]) - ctx.scene_layout()[1]  # the scene's own per-frame triangles (its moving boxes)
     ctx.set_geometry(3, vtx, vtx, idx, ext, mqhip.MQ_GEO_OPAQUE)  # slot 3, not static: per-frame geometry
     ctx.commit()
     assert ctx.commit_device_count() == 1
-    _check_tree(ctx, n)
+    _check_tree(ctx, own + n)
     orc.mirror_scene(ctx, o); o.commit(1)
     org = (c + rng.uniform(-40, 40, (30000, 3))).astype(np.float32)
-    d = rng.normal(size=(30000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d = (c + [3, 3, 1] + rng.uniform(-6, 6, (30000, 3))) - org  # aimed at the stack of triangles
+    d[::3] = rng.normal(size=(10000, 3))                        # (a third anywhere)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     p0, t0, _ = o.trace_rays(org, d)
     p1, t1, _ = ctx.trace_rays(org, d)
     assert np.array_equal(p0, p1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
     assert ((p0 >> 28) == 3).sum() > 100
+    ctx.dyn_begin(); ctx.dyn_end(2)  # (the scene's own per-frame boxes go: slot 3 is all the per-frame geometry there is)
     for k in (1, 2):  # the smallest trees: one triangle (the root's only child is a leaf), two
         ctx.set_geometry(3, vtx[:3 * k], vtx[:3 * k], idx[:k], ext[:k], mqhip.MQ_GEO_OPAQUE)
         ctx.commit()
         assert _check_tree(ctx, k) == 1
+        o = orc.Oracle(orc.params_from_ctx(ctx, ctx.get_constants()))  # (a fresh one: mirror_scene does not clear the slot that went)
         orc.mirror_scene(ctx, o); o.commit(1)
         p0, t0, _ = o.trace_rays(org, d)
         p1, t1, _ = ctx.trace_rays(org, d)

@@ -15,6 +15,8 @@ for P in counts:
     ctx.json_defaults()
     for k, v in {"randomize seed": 0, "seed": 0x5EED, "spp": 1, "max path length": 3}.items():
         ctx.set_property(k, v)
+    if os.environ.get("MQ_DYN_BVH"):  # who builds the per-frame tree: host (default) | device | auto
+        ctx.set_property("per-frame BVH", os.environ["MQ_DYN_BVH"])
     ctx.synth_scene("synth_sepulcher", 2); ctx.commit(); ctx.connect(1920, 1080)
     u0 = ctx.synth_camera(0)
     parts = np.zeros(P, mqhip.PARTICLE_DTYPE)
@@ -54,6 +56,6 @@ for P in counts:
     ctx.sync()
     ms = (time.perf_counter() - t0) * 10.0
     n_tris = ctx.scene_stats()["n_tris"]
-    print("particles %6d: %.3f ms per frame (wall, 100 frames); host: producer %.3f + commit %.3f + mq_process %.3f ms; scene triangles %d; commits that did not wait %d of %d"
-          % (P, ms, host[0] * 10, host[1] * 10, host[2] * 10, n_tris, ctx.commit_async_count(), ctx.commit_counts()[1]), flush=True)
+    print("particles %6d: %.3f ms per frame (wall, 100 frames); host: producer %.3f + commit %.3f + mq_process %.3f ms; scene triangles %d; commits that did not wait %d of %d, trees built on the device %d"
+          % (P, ms, host[0] * 10, host[1] * 10, host[2] * 10, n_tris, ctx.commit_async_count(), ctx.commit_counts()[1], ctx.commit_device_count()), flush=True)
     ctx.close()
