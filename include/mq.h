@@ -186,7 +186,7 @@ int mq_scene_commit_counts(const mq_ctx* ctx, uint32_t* full, uint32_t* per_fram
 int mq_scene_commit_async_count(const mq_ctx* ctx, uint32_t* n);
 /* how many per-frame commits had their tree built on the device (property "per-frame BVH": "host" | "device" | "auto"; the
  * reference's per-frame acceleration structure is built by the Vulkan driver on the GPU, quake_node.cpp:896-983 + the graph's
- * builder node).  "auto": on the device from 4096 per-frame triangles on.  Results do not depend on who builds a tree. */
+ * builder node).  "auto", the default: on the device from 12 288 per-frame triangles on (below that the host's SAH tree is built in time and is the better tree).  Results do not depend on who builds a tree. */
 int mq_scene_commit_device_count(const mq_ctx* ctx, uint32_t* n);
 /* QuakeRenderInfo::constant + constant_data_update, src/game/quake_node.hpp:62-84 */
 int mq_set_constants(mq_ctx* ctx, const mq_constants* c);

@@ -75,7 +75,7 @@ struct MqProps {
     bool debug_output_connected = false; // the reference derives this from the graph wiring (render_mcpg.cpp:182-183)
     bool freeze_learning = false; // test hook, not a reference property
     bool log_learning = false;    // test hook, not a reference property
-    int dyn_bvh = 0;                 // "per-frame BVH": who builds the tree of the per-frame geometry: 0 host (SAH on the worker pool), 1 device (mq_devbvh.hip), 2 auto (device from MQ_DEVBVH_AUTO_TRIS triangles on)
+    int dyn_bvh = 2;                 // "per-frame BVH": who builds the tree of the per-frame geometry: 0 host (SAH on the worker pool), 1 device (mq_devbvh.hip), 2 auto (device from 12 288 per-frame triangles on; MQ_DEVBVH_AUTO_TRIS)
     bool lc_try_lock = false;        // the reference's light-cache try-lock (contended updates cancelled, light_cache.glsl:59-64) instead of the lock-free 8-byte publish
     bool lc_lock_statistics = false; // the reference's light-cache try-lock with per-cell counters + last_update_count per slot (for the state dumps)
     int overlap_camera_rays = 1;      // scheduling of this build: the camera rays of frame n + 1 traced beside kernels of frame n, on a low-priority stream

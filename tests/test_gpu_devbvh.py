@@ -145,8 +145,8 @@ def test_device_built_tree_of_coincident_and_degenerate_triangles(mqlib):
 
 
 def test_frames_do_not_depend_on_who_builds_the_per_frame_tree(mqlib):
-    """Eight frames, each with its own particle cloud (300 .. 1500 particles), issued back to back: "per-frame BVH" = device against host --
-    every node output of the last frame and the image accumulated over all of them bit-identical; "auto" takes the device from 4096
+    """Eight frames, each with its own particle cloud (1000 .. 5000 particles), issued back to back: "per-frame BVH" = device against host --
+    every node output of the last frame and the image accumulated over all of them bit-identical; "auto" takes the device from 12 288
     triangles on."""
     import mqhip
     outs = {}
@@ -157,8 +157,12 @@ def test_frames_do_not_depend_on_who_builds_the_per_frame_tree(mqlib):
         u0, view = _view(ctx)
         eye = np.array([u0.cam_x[0], u0.cam_x[1], u0.cam_x[2]]); fwd = np.array([u0.cam_w[0], u0.cam_w[1], u0.cam_w[2]])
         rng = np.random.default_rng(77)
+        parts = _cloud(rng, 5000, eye + fwd * 40.0, 30.0)  # (grows the regions beyond the 16 384 triangles of the first commit: a full commit, on the host in every mode)
+        ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, 0.0, 0.0); ctx.dyn_end(2)
+        ctx.commit()
+        assert ctx.commit_device_count() == 0 and ctx.commit_counts() == (2, 0)
         for f in range(8):
-            parts = _cloud(rng, 300 + 400 * (f % 4), eye + fwd * 40.0, 30.0)
+            parts = _cloud(rng, (1000, 2000, 3500, 5000)[f % 4], eye + fwd * 40.0, 30.0)
             ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, f / 60.0, (f - 1) / 60.0); ctx.dyn_end(2)
             ctx.commit()
             ctx.process(u0); ctx.post_process()

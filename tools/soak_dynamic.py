@@ -16,17 +16,19 @@ PROPS = {"randomize seed": 0, "seed": 0x5EED, "reference mode": 1, "spp": 1, "ma
          "restir: randomize seed": 0, "restir: spp": 1}
 
 
-def make():
+def make(dyn_bvh=None):
     c = mqhip.Context(0)
     c.header_defaults()
     c.synth_scene("synth_start", 4)
     for k, v in PROPS.items():
         c.set_property(k, v)
+    if dyn_bvh:
+        c.set_property("per-frame BVH", dyn_bvh)
     c.commit(); c.connect(W, H)
     return c
 
 
-a, b = make(), make()
+a, b = make(os.environ.get("MQ_DYN_BVH")), make("host")  # MQ_DYN_BVH=device: the pipelined context's per-frame trees are built on the device, the reference context's on the host
 rng = np.random.default_rng(11)
 u0 = a.synth_camera(0)
 eye = np.array([u0.cam_x[0], u0.cam_x[1], u0.cam_x[2]]); fwd = np.array([u0.cam_w[0], u0.cam_w[1], u0.cam_w[2]])
@@ -77,8 +79,8 @@ for f in range(frames):
         same = all(np.array_equal(a.read_output(o), b.read_output(o)) for o in (mqhip.OUT_HITS, mqhip.OUT_IRRADIANCE, mqhip.OUT_GB_MV))
         checked += 1; bad += not same
         if not same or checked % 10 == 0:
-            print("frame %d: %d compared, %d differ; commits full / per-frame / without waiting: %s / %d; clouds beyond the region %d, static changes %d; %.0f s"
-                  % (f + 1, checked, bad, a.commit_counts(), a.commit_async_count(), big, statics, time.time() - t0), flush=True)
+            print("frame %d: %d compared, %d differ; commits full / per-frame / without waiting / trees built on the device: %s / %d / %d; clouds beyond the region %d, static changes %d; %.0f s"
+                  % (f + 1, checked, bad, a.commit_counts(), a.commit_async_count(), a.commit_device_count(), big, statics, time.time() - t0), flush=True)
 print("done: %d frames, %d compared, %d differ" % (frames, checked, bad))
 a.close(); b.close()
 sys.exit(1 if bad else 0)
