@@ -7,7 +7,7 @@
 //
 //   bounds        centroid box + largest coordinate                      (wave reductions, ordered-integer atomics)
 //   codes         30-bit Morton code of every centroid
-//   sort          hipcub::DeviceRadixSort::SortPairs (code, triangle)
+//   sort          rocprim::radix_sort_pairs (code, triangle)
 //   hierarchy     binary radix tree over the sorted codes (Karras 2012: one thread per internal node)
 //   fit           boxes bottom-up: the second thread to arrive at a node merges its children (acq_rel counters at agent scope:
 //                 the XCDs' L2s are not coherent with each other)
@@ -23,7 +23,8 @@
 #include "mq_devbvh.h"
 
 #include <algorithm>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 __device__ __forceinline__ uint32_t ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); } // order-preserving
@@ -250,7 +251,7 @@ __global__ void db_finish(MqDevBvh A) { // anything left in the queue after the 
 size_t mq_device_bvh_sort_bytes(uint32_t n) {
     size_t bytes = 0;
     uint32_t* k = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, k, k, k, (int)n, 0, 30, nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)n, 0u, 30u, (hipStream_t) nullptr);
     return bytes;
 }
 
@@ -265,7 +266,7 @@ int mq_launch_device_bvh(const MqDevBvh& A, void* sort_tmp, size_t sort_bytes, h
     db_init<<<1, 64, 0, s>>>(A);
     db_bounds<<<grid, 256, 0, s>>>(A);
     db_codes<<<grid, 256, 0, s>>>(A);
-    e = hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, A.keys0, A.keys1, A.vals0, A.vals1, (int)A.n, 0, 30, s);
+    e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, A.keys0, A.keys1, A.vals0, A.vals1, (size_t)A.n, 0u, 30u, s);
     if (e != hipSuccess) return (int)e;
     if (A.n > 1) db_hierarchy<<<grid, 256, 0, s>>>(A);
     db_fit<<<grid, 256, 0, s>>>(A);
