@@ -173,12 +173,17 @@ int mq_dyn_add_particles(mq_ctx* ctx, const mq_particle* parts, uint32_t n, cons
             const double ax = xr.next(), ay = xr.next(), az = xr.next();
             const V3 axis = normalize(V3{(float)ax, (float)ay, (float)az});
             const float ang = (float)((rand_angle + cl_time * 0.001 * speed) * 2 * M_PI), prev_ang = (float)((rand_angle + prev_cl_time * 0.001 * speed) * 2 * M_PI);
+            // only the last pass's vertices survive: the first two only advance the random stream (3 draws per vertex); the rotation's
+            // sine and cosine are per pass, not per vertex (the values rodrigues() computes: same expressions, same bits)
+            if (l < 2) { for (int k = 0; k < 12; k++) (void)xr.next(); continue; }
+            const float ca = std::cos(ang), sa = std::sin(ang), cp = std::cos(prev_ang), sp = std::sin(prev_ang);
+            auto rot = [&](V3 v, float c, float s) { return (v * c + cross(axis, v) * s) + axis * (dot(axis, v) * (1.0f - c)); };
             for (int k = 0; k < 4; k++) {
                 const float vertex_offset = (float)(0.5 * ((xr.next() - 0.5) + (xr.next() - 0.5)));
                 const float rand_offset_scale = (float)xr.next();
                 const V3 local = (voff[k] * scale) * (1.0f + rand_offset_scale) + V3{vertex_offset, vertex_offset, vertex_offset};
-                vert[k] = (org + V3{particle_offset, particle_offset, particle_offset}) + rodrigues(local, axis, ang);
-                prev_vert[k] = (prev_org + V3{particle_offset, particle_offset, particle_offset}) + rodrigues(local, axis, prev_ang);
+                vert[k] = (org + V3{particle_offset, particle_offset, particle_offset}) + rot(local, ca, sa);
+                prev_vert[k] = (prev_org + V3{particle_offset, particle_offset, particle_offset}) + rot(local, cp, sp);
             }
         }
         const uint32_t base = (uint32_t)(v_at / 3 + 4 * pi);
