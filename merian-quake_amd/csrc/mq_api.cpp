@@ -734,13 +734,13 @@ static void materialize_mirror(const mq_ctx* cc) { // (the inspection calls take
         const size_t ns = c->n_static_nodes, ts = c->n_static_tris, ls = c->n_static_leaves, td = c->db_tris[p];
         const size_t on = ns + (size_t)p * c->dyn_cap_nodes, ot = ts + (size_t)p * c->dyn_cap_tris, ol = ls + (size_t)p * c->dyn_cap_tris;
         (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
-        const size_t nd = td ? c->db_ctr_host[p][MQ_DB_NODES] : 0;
-        c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + td);
+        const size_t nd = td ? c->db_ctr_host[p][MQ_DB_NODES] : 0, ld = td ? c->db_ctr_host[p][MQ_DB_LEAVES] : 0;
+        c->nodes.resize(ns + nd); c->tris.resize(ts + td); c->leaves.resize(ls + ld);
         if (nd) (void)hipMemcpy(c->nodes.data() + ns, (const MqNode*)c->d_nodes.p + on, nd * sizeof(MqNode), hipMemcpyDeviceToHost);
         if (td) (void)hipMemcpy(c->tris.data() + ts, (const MqTri*)c->d_tris.p + ot, td * sizeof(MqTri), hipMemcpyDeviceToHost);
-        if (td) (void)hipMemcpy(c->leaves.data() + ls, (const MqLeafRec*)c->d_leaves.p + ol, td * sizeof(MqLeafRec), hipMemcpyDeviceToHost);
+        if (ld) (void)hipMemcpy(c->leaves.data() + ls, (const MqLeafRec*)c->d_leaves.p + ol, ld * sizeof(MqLeafRec), hipMemcpyDeviceToHost);
         for (size_t j = 0; j < nd; j++) { MqNode& n = c->nodes[ns + j]; n.child_base -= (uint32_t)(on - ns); n.tri_base -= (uint32_t)(ol - ls); } // the contiguous numbering
-        for (size_t j = 0; j < td; j++) c->leaves[ls + j].tri0 -= (uint32_t)(ot - ts);
+        for (size_t j = 0; j < ld; j++) c->leaves[ls + j].tri0 -= (uint32_t)(ot - ts);
         c->mirror_pending = false;
         return;
     }
@@ -878,11 +878,14 @@ int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
     const size_t ns = c->s_nodes.size(), ts = c->s_tris.size(), ls = c->s_leaves.size(), td = flat.size();
     int r;
     if ((r = ensure_upload_stream(c))) return r;
+    static const bool times = getenv("MQ_DEBUG_COMMIT_TIMES") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     const int p = c->dyn_parity ^ 1;
     if (c->scene_used_mixed[p]) { HIPCHK(c, hipDeviceSynchronize()); }
     else if (c->scene_used_valid[p]) HIPCHK(c, hipEventSynchronize(c->ev_scene_used[p]));
     c->scene_used_valid[p] = false; c->scene_used_mixed[p] = false;
     HIPCHK(c, hipStreamSynchronize(c->up_stream));
+    const auto t_1 = std::chrono::steady_clock::now();
     for (int k = 0; k < 2; k++) if (c->db_ctr_pending[k]) { // what the last builds reported
         c->db_ctr_pending[k] = false;
         if (c->db_ctr_host[k][MQ_DB_ERR]) return fail(c, MQ_EHIP, "the device builder of the per-frame tree flagged an overflow (flags " + std::to_string(c->db_ctr_host[k][MQ_DB_ERR]) + ")");
@@ -956,6 +959,8 @@ int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
         c->db_ctr_pending[p] = true;
     }
     HIPCHK(c, hipEventRecord(c->ev_uploaded, c->up_stream));
+    if (times) { auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "commit (per-frame, region %d, tree on the device, %zu triangles): wait for the region's last reader and the upload stream %.3f ms, stage + enqueue copies and the build %.3f\n", p, td, ms(t_0, t_1), ms(t_1, std::chrono::steady_clock::now())); }
     c->uploaded_valid = true;
     c->scene.n_nodes = (uint32_t)(on + (td ? 1 : 0)); c->scene.n_tris = (uint32_t)(ot + td);
     c->scene.dyn_root = td ? (uint32_t)on : MQ_NIL;

@@ -13,7 +13,7 @@ struct MqDevBvh {
     uint2* queue0; uint2* queue1;                                         // wide nodes to expand: (binary id, node number within the region)
     uint32_t* ctr;                                                        // MQ_DB_* words
 };
-enum { MQ_DB_Q0 = 0, MQ_DB_NODES = 3, MQ_DB_LEAVES = 4, MQ_DB_ERR = 5, MQ_DB_LO = 6, MQ_DB_HI = 9, MQ_DB_MAXABS = 12, MQ_DB_DEPTH = 13, MQ_DB_WORDS = 16 };
+enum { MQ_DB_Q0 = 0, MQ_DB_NODES = 3, MQ_DB_LEAVES = 4, MQ_DB_ERR = 5, MQ_DB_LO = 6, MQ_DB_HI = 9, MQ_DB_MAXABS = 12, MQ_DB_DEPTH = 13, MQ_DB_PRIMS = 14 /* primitives (leaf records) */, MQ_DB_TRIS = 15, MQ_DB_WORDS = 16 };
 #define MQ_DB_LEVELS 64 // collapse launches per build (a launch whose queue is empty costs ~2 us); a tree deeper than this is flagged
 
 
