@@ -896,7 +896,7 @@ int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
     if (c->db_cap < td) {
         const uint32_t cap = (uint32_t)std::max<size_t>(td + td / 2, 16384);
         const size_t bytes = al((size_t)cap * sizeof(MqTri)) + 4 * al((size_t)cap * 4) + al((size_t)cap * 2 * 4) + al((size_t)cap * 8) + al((size_t)cap * 2 * 24) + al((size_t)cap * 4)
-                           + 2 * al((size_t)cap * 8) + al(MQ_DB_WORDS * 4) + al(mq_device_bvh_sort_bytes(cap));
+                           + 3 * al((size_t)cap * 8) + al(MQ_DB_WORDS * 4) + al(mq_device_bvh_sort_bytes(cap));
         if ((r = dev_alloc(c, c->d_db_scratch, bytes))) return r;
         c->db_cap = cap;
     }
@@ -928,7 +928,7 @@ int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
       A.in = (const MqTri*)take(cap * sizeof(MqTri));
       A.keys0 = (uint32_t*)take(cap * 4); A.keys1 = (uint32_t*)take(cap * 4); A.vals0 = (uint32_t*)take(cap * 4); A.vals1 = (uint32_t*)take(cap * 4);
       A.parent = (int*)take(cap * 2 * 4); A.child = (int2*)take(cap * 8); A.box = (float*)take(cap * 2 * 24); A.flag = (uint32_t*)take(cap * 4);
-      A.queue0 = (uint2*)take(cap * 8); A.queue1 = (uint2*)take(cap * 8); A.ctr = (uint32_t*)take(MQ_DB_WORDS * 4); }
+      A.queue0 = (uint2*)take(cap * 8); A.queue1 = (uint2*)take(cap * 8); A.leaf_at = (uint2*)take(cap * 8); A.ctr = (uint32_t*)take(MQ_DB_WORDS * 4); }
     void* sort_tmp = (char*)A.ctr + al(MQ_DB_WORDS * 4);
     const size_t sort_bytes = mq_device_bvh_sort_bytes(c->db_cap);
     if ((r = push((void*)A.in, flat.data(), td * sizeof(MqTri)))) return r;

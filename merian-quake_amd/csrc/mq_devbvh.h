@@ -10,6 +10,7 @@ struct MqDevBvh {
     MqSceneDev sc;                                                        // per-slot extra data and texture descriptors (shading records)
     uint32_t *keys0, *keys1, *vals0, *vals1;                              // codes and triangle numbers, before / after the sort
     int* parent; int2* child; float* box; uint32_t* flag;                 // binary tree: ids [0, n-1) internal, [n-1, 2n-1) leaves
+    uint2* leaf_at;                                                       // per primitive: (leaf record, first triangle) it was given by the collapse
     uint2* queue0; uint2* queue1;                                         // wide nodes to expand: (binary id, node number within the region)
     uint32_t* ctr;                                                        // MQ_DB_* words
 };

@@ -209,15 +209,18 @@ __global__ __launch_bounds__(128) void db_collapse(MqDevBvh A, int level) {
         const float pc[3] = {0.5f * (pb[0] + pb[3]), 0.5f * (pb[1] + pb[4]), 0.5f * (pb[2] + pb[5])};
         float dcen[8][3];
         for (int i = 0; i < nc; i++) { const float* cb = A.box + 6 * (size_t)ch[i]; for (int a = 0; a < 3; a++) dcen[i][a] = 0.5f * (cb[a] + cb[3 + a]) - pc[a]; }
+        // a child takes the slot of its octant (slot bit k set = it lies on the high side of axis k) or, if that one is taken, the next free one: the
+        // children farthest from the parent's centre choose first.  (The host builder runs the best-pair auction of the CWBVH paper, 512 evaluations per
+        // node; one thread per node cannot afford that on the device: a level took 0.1 ms.)
         int slot_child[8]; for (int s = 0; s < 8; s++) slot_child[s] = -1;
         uint32_t used = 0;
         for (int it = 0; it < nc; it++) {
-            int bi = -1, bs = -1; float bc = -INFINITY;
-            for (int i = 0; i < nc; i++) if (!((used >> i) & 1u)) for (int s = 0; s < 8; s++) if (slot_child[s] < 0) {
-                const float c = ((s & 1) ? dcen[i][0] : -dcen[i][0]) + ((s & 2) ? dcen[i][1] : -dcen[i][1]) + ((s & 4) ? dcen[i][2] : -dcen[i][2]);
-                if (c > bc || bi < 0) { bc = c; bi = i; bs = s; }
-            }
-            used |= 1u << bi; slot_child[bs] = ch[bi];
+            int bi = 0; float bd = -1.0f;
+            for (int i = 0; i < nc; i++) if (!((used >> i) & 1u)) { const float d = fabsf(dcen[i][0]) + fabsf(dcen[i][1]) + fabsf(dcen[i][2]); if (d > bd || bd < 0.0f) { bd = d; bi = i; } }
+            used |= 1u << bi;
+            int sl = (dcen[bi][0] > 0.0f ? 1 : 0) | (dcen[bi][1] > 0.0f ? 2 : 0) | (dcen[bi][2] > 0.0f ? 4 : 0);
+            while (slot_child[sl] >= 0) sl = (sl + 1) & 7;
+            slot_child[sl] = ch[bi];
         }
         MqNode node; memset(&node, 0, sizeof node);
         float lo[3], hi[3]; int ex[3];
@@ -264,32 +267,41 @@ __global__ __launch_bounds__(128) void db_collapse(MqDevBvh A, int level) {
                 node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
                 qout[q_at + next_child] = make_uint2((uint32_t)c, child_rel + next_child);
                 next_child++;
-            } else { // one leaf record of one or two triangles; triangles and shading records in the same order
+            } else { // one leaf record of one or two triangles: the collapse only says WHERE (db_records writes them, a thread per primitive)
                 const uint32_t desc = A.vals1[c - (m - 1)];
-                const uint32_t ti = A.tri_base + tris_rel + tri_off;
-                const MqTri t = A.in[desc & ~MQ_DB_PAIRED];
-                MqLeafRec r; memset(&r, 0, sizeof r);
-                for (int a = 0; a < 3; a++) { r.v[0][a] = t.v0[a]; r.v[1][a] = t.v1[a]; r.v[2][a] = t.v2[a]; r.v[3][a] = t.v0[a]; }
-                r.key0 = t.key; r.key1 = MQ_NIL; r.tri0 = ti; r.sel = (t.flags & MQ_TRI_ANYHIT) ? 0x10000u : 0u;
-                A.tris[ti] = t;
-                A.shade[ti] = shade_of(A, t.key);
-                tri_off++;
-                if (desc & MQ_DB_PAIRED) {
-                    const MqTri u = A.in[(desc & ~MQ_DB_PAIRED) + 1u];
-                    int fresh; const int sel = pair_sel(t, u, fresh);
-                    if (fresh >= 0) { const float* bv[3] = {u.v0, u.v1, u.v2}; for (int a = 0; a < 3; a++) r.v[3][a] = bv[fresh][a]; }
-                    r.key1 = u.key;
-                    r.sel |= (uint32_t)sel | MQ_LEAF_HAS_B | ((u.flags & MQ_TRI_ANYHIT) ? 0x20000u : 0u);
-                    A.tris[ti + 1u] = u;
-                    A.shade[ti + 1u] = shade_of(A, u.key);
-                    tri_off++;
-                }
-                A.leaves[A.leaf_base + leaf_rel + rec_off] = r;
+                A.leaf_at[c - (m - 1)] = make_uint2(A.leaf_base + leaf_rel + rec_off, A.tri_base + tris_rel + tri_off);
+                tri_off += (desc & MQ_DB_PAIRED) ? 2u : 1u;
                 node.meta[s] = (uint8_t)((1u << 5) | rec_off);
                 rec_off++;
             }
         }
         if (out_index < A.node_cap) A.nodes[A.node_base + out_index] = node;
+    }
+}
+
+// leaf record, triangles and shading records of every primitive, where the collapse put them
+__global__ __launch_bounds__(256) void db_records(MqDevBvh A) {
+    const uint32_t m = A.ctr[MQ_DB_PRIMS];
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+        const uint2 at = A.leaf_at[k];
+        if (at.x == MQ_NIL) continue; // (a leaf the collapse never reached: only in a tree deeper than MQ_DB_LEVELS, which is flagged)
+        const uint32_t desc = A.vals1[k], ti = at.y;
+        const MqTri t = A.in[desc & ~MQ_DB_PAIRED];
+        MqLeafRec r; memset(&r, 0, sizeof r);
+        for (int a = 0; a < 3; a++) { r.v[0][a] = t.v0[a]; r.v[1][a] = t.v1[a]; r.v[2][a] = t.v2[a]; r.v[3][a] = t.v0[a]; }
+        r.key0 = t.key; r.key1 = MQ_NIL; r.tri0 = ti; r.sel = (t.flags & MQ_TRI_ANYHIT) ? 0x10000u : 0u;
+        A.tris[ti] = t;
+        A.shade[ti] = shade_of(A, t.key);
+        if (desc & MQ_DB_PAIRED) {
+            const MqTri u = A.in[(desc & ~MQ_DB_PAIRED) + 1u];
+            int fresh; const int sel = pair_sel(t, u, fresh);
+            if (fresh >= 0) { const float* bv[3] = {u.v0, u.v1, u.v2}; for (int a = 0; a < 3; a++) r.v[3][a] = bv[fresh][a]; }
+            r.key1 = u.key;
+            r.sel |= (uint32_t)sel | MQ_LEAF_HAS_B | ((u.flags & MQ_TRI_ANYHIT) ? 0x20000u : 0u);
+            A.tris[ti + 1u] = u;
+            A.shade[ti + 1u] = shade_of(A, u.key);
+        }
+        A.leaves[at.x] = r;
     }
 }
 
@@ -312,6 +324,7 @@ int mq_launch_device_bvh(const MqDevBvh& A, void* sort_tmp, size_t sort_bytes, h
     const int grid = (int)std::min<uint32_t>((A.n + 255u) / 256u, 2048u);
     hipError_t e = hipMemsetAsync(A.nodes + A.node_base, 0, (size_t)std::min(A.n, A.node_cap) * sizeof(MqNode), s);
     if (e == hipSuccess && A.n > 1) e = hipMemsetAsync(A.flag, 0, (size_t)(A.n - 1) * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(A.leaf_at, 0xff, (size_t)A.n * 8, s);
     if (e != hipSuccess) return (int)e;
     db_init<<<1, 64, 0, s>>>(A);
     db_bounds<<<grid, 256, 0, s>>>(A);
@@ -322,6 +335,7 @@ int mq_launch_device_bvh(const MqDevBvh& A, void* sort_tmp, size_t sort_bytes, h
     if (A.n > 1) db_hierarchy<<<grid, 256, 0, s>>>(A);
     db_fit<<<grid, 256, 0, s>>>(A);
     for (int level = 0; level < MQ_DB_LEVELS; level++) db_collapse<<<(int)std::min<uint32_t>((A.n + 127u) / 128u, 1024u), 128, 0, s>>>(A, level);
+    db_records<<<grid, 256, 0, s>>>(A);
     db_finish<<<1, 64, 0, s>>>(A);
     return (int)hipGetLastError();
 }
