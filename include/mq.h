@@ -377,6 +377,9 @@ typedef struct mq_sprite_instance { float origin[3], prev_origin[3], angles[3]; 
 int mq_dyn_begin(mq_ctx* ctx);
 int mq_dyn_add_particles(mq_ctx* ctx, const mq_particle* particles, uint32_t n, const mq_view* view, uint32_t texnum_blood, uint32_t texnum_explosion, double cl_time, double prev_cl_time); /* add_particles, quake_helpers.cpp:50-216 */
 int mq_dyn_add_alias(mq_ctx* ctx, int alias_model, const mq_alias_instance* inst);                                   /* add_geo_alias, :218-359 */
+/* n entities at once, on the library's worker pool (the reference runs add_geo_alias under a parallel_for over the visible entities,
+ * quake_node.cpp:904-938): the same triangles, in the same order, as n calls of mq_dyn_add_alias */
+int mq_dyn_add_alias_batch(mq_ctx* ctx, const int* alias_models, const mq_alias_instance* inst, uint32_t n);
 int mq_dyn_add_sprite(mq_ctx* ctx, int sprite_model, const mq_sprite_instance* inst, const mq_view* view);           /* add_geo_sprite, :471-626 */
 int mq_dyn_add_brush_model(mq_ctx* ctx, int bsp_model, const float origin[3], const float angles[3], const float prev_origin[3], const float prev_angles[3]); /* add_geo_brush for an entity, :362-469 */
 int mq_dyn_end(mq_ctx* ctx, int slot); /* -> mq_scene_set_geometry(slot, ..., flags 0): alpha tests apply, rebuilt every frame (quake_node.cpp:969-981) */

@@ -115,6 +115,7 @@ class RendererMarkovChainHIP {
         check(mq_dyn_add_particles(ctx_, p, n, &view, texnum_blood, texnum_explosion, cl_time, prev_cl_time));
     }
     void dyn_add_alias(int model, const mq_alias_instance& inst) { check(mq_dyn_add_alias(ctx_, model, &inst)); }
+    void dyn_add_alias_batch(const int* models, const mq_alias_instance* insts, uint32_t n) { check(mq_dyn_add_alias_batch(ctx_, models, insts, n)); } // the visible entities at once, on the worker pool
     void dyn_add_sprite(int model, const mq_sprite_instance& inst, const mq_view& view) { check(mq_dyn_add_sprite(ctx_, model, &inst, &view)); }
     void dyn_add_brush_model(int model, const float origin[3], const float angles[3], const float prev_origin[3], const float prev_angles[3]) {
         check(mq_dyn_add_brush_model(ctx_, model, origin, angles, prev_origin, prev_angles));

@@ -257,27 +257,24 @@ int mq_dyn_add_sprite(mq_ctx* ctx, int sprite_model, const mq_sprite_instance* i
 }
 
 // add_geo_alias, quake_helpers.cpp:218-359
-int mq_dyn_add_alias(mq_ctx* ctx, int alias_model, const mq_alias_instance* in) {
-    if (!ctx || !in) return MQ_EINVAL;
-    MqProducerState& P = mq_ctx_producers(ctx);
-    if (!P.collecting) return mq_ctx_fail(ctx, MQ_ESTATE, "mq_dyn_add_alias outside mq_dyn_begin / mq_dyn_end");
-    if (alias_model < 0 || (size_t)alias_model >= P.alias.size()) return mq_ctx_fail(ctx, MQ_EINVAL, "unknown alias model");
-    const MqAliasModel& m = P.alias[(size_t)alias_model];
-    if (in->pose1 < 0 || in->pose2 < 0 || (uint32_t)in->pose1 >= m.numposes || (uint32_t)in->pose2 >= m.numposes) return MQ_OK; // "if (f < 0 || f >= hdr->numposes) return"
-    MqHostGeo& g = P.pending;
+namespace {
+// One alias-model entity into caller-provided slices (nv = m.vertindex.size() vertices, m.indexes.size() indices, a third as many extra-data records):
+// the body of add_geo_alias, quake_helpers.cpp:218-359.  `base`: number of the slice's first vertex in the slot.
+void alias_write(const MqAliasModel& m, const mq_alias_instance* in, float* vtx, float* prev, uint32_t* idx, mq_ext* ext, uint32_t base) {
     const V3 fov = {1.0f, in->fovscale > 0.0f ? in->fovscale : 1.0f, in->fovscale > 0.0f ? in->fovscale : 1.0f}; // view model: makes the gun fov independent (:244-246)
-    const float ang[3] = {-in->angles[0], in->angles[1], in->angles[2]}, pang[3] = {-in->prev_angles[0], in->prev_angles[1], in->prev_angles[2]}; // "lerpdata.angles[0] *= -1"; the stored previous angles are already negated ones
+    const float ang[3] = {-in->angles[0], in->angles[1], in->angles[2]}, pang[3] = {-in->prev_angles[0], in->prev_angles[1], in->prev_angles[2]}; // "lerpdata.angles[0] *= -1"; the stored previous angles are already negated the same way
     const M34 mm = entity_matrix(in->origin, ang), pm = entity_matrix(in->prev_origin, pang);
     const V3 so = {m.scale_origin[0] * fov.x, m.scale_origin[1] * fov.y, m.scale_origin[2] * fov.z}, sc = {m.scale[0] * fov.x, m.scale[1] * fov.y, m.scale[2] * fov.z};
-    const uint32_t base = (uint32_t)(g.vtx.size() / 3), nvbo = (uint32_t)m.vertindex.size();
+    const uint32_t nvbo = (uint32_t)m.vertindex.size();
     for (uint32_t v = 0; v < nvbo; v++) {
         const uint8_t* a = &m.trivertexes[4 * ((size_t)m.numverts * (size_t)in->pose1 + m.vertindex[v])];
         const uint8_t* b = &m.trivertexes[4 * ((size_t)m.numverts * (size_t)in->pose2 + m.vertindex[v])];
         auto lerp = [&](float t) { return V3{(float)a[0] * (1.0f - t) + (float)b[0] * t, (float)a[1] * (1.0f - t) + (float)b[1] * t, (float)a[2] * (1.0f - t) + (float)b[2] * t}; };
         auto model = [&](V3 p) { return V3{p.x * sc.x + so.x, p.y * sc.y + so.y, p.z * sc.z + so.z}; };
-        push_vtx(g, mm.apply(model(lerp(in->blend))), pm.apply(model(lerp(in->prev_blend))));
+        const V3 p = mm.apply(model(lerp(in->blend))), q = pm.apply(model(lerp(in->prev_blend)));
+        vtx[3 * v] = p.x; vtx[3 * v + 1] = p.y; vtx[3 * v + 2] = p.z; prev[3 * v] = q.x; prev[3 * v + 1] = q.y; prev[3 * v + 2] = q.z;
     }
-    for (size_t i = 0; i < m.indexes.size(); i++) g.idx.push_back(base + m.indexes[i]);
+    for (size_t i = 0; i < m.indexes.size(); i++) idx[i] = base + m.indexes[i];
     const size_t nskins = m.skin_texnum.size();
     const size_t sk = nskins ? (size_t)std::min<int>(std::max(in->skin, 0), (int)nskins - 1) : 0;
     for (size_t t = 0; t < m.indexes.size() / 3; t++) {
@@ -285,15 +282,40 @@ int mq_dyn_add_alias(mq_ctx* ctx, int alias_model, const mq_alias_instance* in) 
         uint32_t n0, n1, n2;
         if (nskins && m.skin_norm_texnum[sk]) { n0 = (m.skin_gloss_texnum[sk] & 0xffffu) | (m.skin_norm_texnum[sk] << 16); n1 = 0xffffffffu; n2 = 0; } // pack_uint32(gloss, norm): marks "use the normal map"
         else {
-            const float* p0 = &g.vtx[3 * (size_t)(base + i0)]; const float* p1 = &g.vtx[3 * (size_t)(base + i1)]; const float* p2 = &g.vtx[3 * (size_t)(base + i2)];
+            const float* p0 = &vtx[3 * (size_t)i0]; const float* p1 = &vtx[3 * (size_t)i1]; const float* p2 = &vtx[3 * (size_t)i2];
             const V3 a = {p0[0], p0[1], p0[2]}, b = {p1[0], p1[1], p1[2]}, c = {p2[0], p2[1], p2[2]};
             n0 = n1 = n2 = encode_normal(normalize(cross(c - a, b - a)));
             if (n1 == 0xffffffffu) n1 = n0 = n2 = 0xfffffffeu; // never the brush-model marker
         }
         const float iw = 1.0f / (float)m.skinwidth, ih = 1.0f / (float)m.skinheight;
-        g.ext.push_back(make_ext(texnum_alpha(nskins ? m.skin_texnum[sk] : 0u, false), (uint16_t)(nskins ? m.skin_fb_texnum[sk] : 0u), n0, n1, n2,
-                                 (m.st[2 * i0] + 0.5f) * iw, (m.st[2 * i0 + 1] + 0.5f) * ih, (m.st[2 * i1] + 0.5f) * iw, (m.st[2 * i1 + 1] + 0.5f) * ih, (m.st[2 * i2] + 0.5f) * iw, (m.st[2 * i2 + 1] + 0.5f) * ih));
+        ext[t] = make_ext(texnum_alpha(nskins ? m.skin_texnum[sk] : 0u, false), (uint16_t)(nskins ? m.skin_fb_texnum[sk] : 0u), n0, n1, n2,
+                          (m.st[2 * i0] + 0.5f) * iw, (m.st[2 * i0 + 1] + 0.5f) * ih, (m.st[2 * i1] + 0.5f) * iw, (m.st[2 * i1 + 1] + 0.5f) * ih, (m.st[2 * i2] + 0.5f) * iw, (m.st[2 * i2 + 1] + 0.5f) * ih);
     }
+}
+} // namespace
+
+int mq_dyn_add_alias(mq_ctx* ctx, int alias_model, const mq_alias_instance* in) { return mq_dyn_add_alias_batch(ctx, &alias_model, in, 1); }
+
+// n entities at once, on the worker pool (the reference runs add_geo_alias under a parallel_for over the visible entities, quake_node.cpp:904-938):
+// the same triangles, in the same order, as n calls of mq_dyn_add_alias
+int mq_dyn_add_alias_batch(mq_ctx* ctx, const int* alias_models, const mq_alias_instance* in, uint32_t n) {
+    if (!ctx || (n && (!alias_models || !in))) return MQ_EINVAL;
+    MqProducerState& P = mq_ctx_producers(ctx);
+    if (!P.collecting) return mq_ctx_fail(ctx, MQ_ESTATE, "mq_dyn_add_alias outside mq_dyn_begin / mq_dyn_end");
+    for (uint32_t e = 0; e < n; e++) if (alias_models[e] < 0 || (size_t)alias_models[e] >= P.alias.size()) return mq_ctx_fail(ctx, MQ_EINVAL, "unknown alias model");
+    MqHostGeo& g = P.pending;
+    std::vector<size_t> v_at(n + 1), i_at(n + 1);
+    v_at[0] = g.vtx.size() / 3; i_at[0] = g.idx.size();
+    for (uint32_t e = 0; e < n; e++) {
+        const MqAliasModel& m = P.alias[(size_t)alias_models[e]];
+        const bool skip = in[e].pose1 < 0 || in[e].pose2 < 0 || (uint32_t)in[e].pose1 >= m.numposes || (uint32_t)in[e].pose2 >= m.numposes; // "if (f < 0 || f >= hdr->numposes) return"
+        v_at[e + 1] = v_at[e] + (skip ? 0 : m.vertindex.size()); i_at[e + 1] = i_at[e] + (skip ? 0 : m.indexes.size());
+    }
+    g.vtx.resize(3 * v_at[n]); g.prev_vtx.resize(3 * v_at[n]); g.idx.resize(i_at[n]); g.ext.resize(i_at[n] / 3);
+    mq_parallel_for(n, 1, [&](size_t b, size_t e1) {
+        for (size_t e = b; e < e1; e++) if (v_at[e + 1] != v_at[e] || i_at[e + 1] != i_at[e])
+            alias_write(P.alias[(size_t)alias_models[e]], &in[e], &g.vtx[3 * v_at[e]], &g.prev_vtx[3 * v_at[e]], &g.idx[i_at[e]], &g.ext[i_at[e] / 3], (uint32_t)v_at[e]);
+    });
     return MQ_OK;
 }
 

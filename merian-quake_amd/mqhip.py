@@ -162,6 +162,7 @@ def load_library(path=None):
         "mq_dyn_begin": (i32, [P]),
         "mq_dyn_add_particles": (i32, [P, vp, u32, C.POINTER(View), u32, u32, C.c_double, C.c_double]),
         "mq_dyn_add_alias": (i32, [P, i32, C.POINTER(AliasInstance)]),
+        "mq_dyn_add_alias_batch": (i32, [P, C.POINTER(C.c_int), C.POINTER(AliasInstance), C.c_uint32]),
         "mq_dyn_add_sprite": (i32, [P, i32, C.POINTER(SpriteInstance), C.POINTER(View)]),
         "mq_dyn_add_brush_model": (i32, [P, i32, f32p, f32p, f32p, f32p]),
         "mq_dyn_end": (i32, [P, i32]),
@@ -456,6 +457,12 @@ class Context:
 
     def dyn_add_alias(self, model, inst):
         self._chk(self.lib.mq_dyn_add_alias(self.h, model, C.byref(inst)))
+
+    def dyn_add_alias_batch(self, models, insts):
+        """n entities at once (on the library's worker pool): the same triangles as n calls of dyn_add_alias"""
+        n = len(insts)
+        ms = (C.c_int * n)(*[int(m) for m in models]); arr = (AliasInstance * n)(*insts)
+        self._chk(self.lib.mq_dyn_add_alias_batch(self.h, ms, arr, n))
 
     def dyn_add_sprite(self, model, inst, view):
         self._chk(self.lib.mq_dyn_add_sprite(self.h, model, C.byref(inst), C.byref(view)))

@@ -264,3 +264,47 @@ def test_per_frame_uniform_matches_oracle(mq, mqlib):
     k = mq.Constants()
     assert lib.mq_constants_fov(__import__("ctypes").byref(k), 90.0) == 0
     assert abs(k.fov_tan_alpha_half - 1.0) < 1e-6 and k.fov == 90.0
+
+
+def test_alias_batch_equals_the_sequence_of_single_calls(mq, tmp_path):
+    """mq_dyn_add_alias_batch (n entities on the worker pool: the reference's parallel_for over the visible entities,
+    quake_node.cpp:904-938) leaves exactly what n calls of mq_dyn_add_alias leave -- vertices, previous vertices, indices,
+    extra data, in the same order -- also behind other per-frame geometry and with an entity whose pose is out of range."""
+    import quake_files as Q
+    rng = np.random.default_rng(21)
+    Q.write_mdl(str(tmp_path / "a.mdl"), rng, numverts=40, numtris=70)
+    Q.write_mdl(str(tmp_path / "b.mdl"), rng, numverts=90, numtris=160, numframes=4)
+    got = []
+    for batched in (False, True):
+        ctx = mq.Context(-1)
+        ctx.header_defaults()
+        ctx.synth_scene("synth_tiny", 2)
+        ma, nxt = ctx.load_mdl(str(tmp_path / "a.mdl"), 300)
+        mb, nxt = ctx.load_mdl(str(tmp_path / "b.mdl"), nxt)
+        r2 = np.random.default_rng(5)
+        models, insts = [], []
+        for e in range(37):
+            ai = mq.AliasInstance()
+            for k in range(3):
+                ai.origin[k] = float(r2.uniform(0, 300)); ai.prev_origin[k] = ai.origin[k] - float(r2.uniform(0, 2))
+                ai.angles[k] = float(r2.uniform(-180, 180)); ai.prev_angles[k] = ai.angles[k] - 3.0
+            ai.pose1, ai.pose2 = int(r2.integers(0, 3)), int(r2.integers(0, 3))
+            ai.blend, ai.prev_blend, ai.skin, ai.fovscale = float(r2.random()), float(r2.random()), int(r2.integers(0, 2)), 1.0
+            if e == 11:
+                ai.pose2 = 99  # out of range: the entity adds nothing
+            models.append(ma if e % 3 else mb); insts.append(ai)
+        ctx.dyn_begin()
+        view = mq.View(); view.forward[0] = 1.0; view.right[1] = -1.0; view.up[2] = 1.0
+        parts = np.zeros(5, mq.PARTICLE_DTYPE); parts["org"] = r2.uniform(0, 100, (5, 3)); parts["seed"] = 7; parts["color_rgba"] = 0xffffff
+        ctx.dyn_add_particles(parts, view, 1, 2, 0.5, 0.4)  # something in the slot before the entities
+        if batched:
+            ctx.dyn_add_alias_batch(models, insts)
+        else:
+            for m, ai in zip(models, insts):
+                ctx.dyn_add_alias(m, ai)
+        ctx.dyn_end(2)
+        got.append(ctx.get_geometry(2))
+    a, b = got
+    assert len(a["idx"]) == 20 + 36 * 0 + sum((70 if e % 3 else 160) for e in range(37) if e != 11)
+    for k in ("vtx", "prev_vtx", "idx", "ext"):
+        assert a[k].tobytes() == b[k].tobytes(), k
