@@ -1,7 +1,9 @@
 """Frame time with PER-FRAME geometry: the bench frame (1920x1080, guided, JSON defaults) with P particles rebuilt, committed
 and rendered every frame (QuakeNode::update_dynamic_geo + the TLAS build of the reference's graph, quake_node.cpp:896-983),
 against the same frames without them.  Wall clock over the whole loop: producer + BVH build + upload + render.
-Usage: python tools/dynamic_frame_time.py [P ...]"""
+Usage: python tools/dynamic_frame_time.py [P ...]
+MQ_ENTITIES=E adds E alias-model entities (a generated 600-vertex / 1200-triangle model, moving and animating) to every frame, through
+mq_dyn_add_alias_batch (MQ_ENTITIES_SINGLE=1: one mq_dyn_add_alias call per entity)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +30,22 @@ for P in counts:
     for k in range(3):
         view.origin[k] = u0.cam_x[k]; view.forward[k] = u0.cam_w[k]; view.up[k] = u0.cam_u[k]
     view.right[0], view.right[1], view.right[2] = 0.0, -1.0, 0.0
+    E = int(os.environ.get("MQ_ENTITIES", "0"))
+    if E:
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import quake_files as Q
+        mdl = os.path.join(tempfile.mkdtemp(), "m.mdl")
+        Q.write_mdl(mdl, np.random.default_rng(3), numverts=600, numtris=1200, numframes=3, skinw=64, skinh=64)
+        alias, _ = ctx.load_mdl(mdl, 300)
+        ctx.commit()
+        ents = []
+        for e in range(E):
+            ai = mqhip.AliasInstance()
+            for k in range(3):
+                ai.origin[k] = float(u0.cam_x[k] + rng.uniform(-400, 400)); ai.prev_origin[k] = ai.origin[k]; ai.angles[k] = float(rng.uniform(0, 360)); ai.prev_angles[k] = ai.angles[k]
+            ai.pose1, ai.pose2, ai.blend, ai.prev_blend, ai.skin, ai.fovscale = 0, 1, 0.0, 0.0, 0, 1.0
+            ents.append(ai)
 
     host = [0.0, 0.0, 0.0, 0.0]  # seconds the host spent in the producer, in the commit, in mq_process, and moving the particles (numpy, the "game")
 
@@ -38,8 +56,19 @@ for P in counts:
             parts["prev_org"] = parts["org"]; parts["org"] = parts["org"] + parts["vel"] / 60.0
         t0 = time.perf_counter()
         host[3] += t0 - tg
-        if P:
-            ctx.dyn_begin(); ctx.dyn_add_particles(parts, view, 1, 2, u.cl_time, u.cl_time - 1 / 60.0); ctx.dyn_end(2)
+        if P or E:
+            ctx.dyn_begin()
+            if P:
+                ctx.dyn_add_particles(parts, view, 1, 2, u.cl_time, u.cl_time - 1 / 60.0)
+            if E:
+                for ai in ents:  # (the "game": every entity turns and animates)
+                    ai.prev_angles[1] = ai.angles[1]; ai.angles[1] += 2.0; ai.prev_blend = ai.blend; ai.blend = (ai.blend + 0.1) % 1.0
+                if os.environ.get("MQ_ENTITIES_SINGLE"):
+                    for ai in ents:
+                        ctx.dyn_add_alias(alias, ai)
+                else:
+                    ctx.dyn_add_alias_batch([alias] * E, ents)
+            ctx.dyn_end(2)
             t1 = time.perf_counter()
             ctx.commit()
         else:
