@@ -171,9 +171,9 @@ int mq_scene_set_texture(mq_ctx* ctx, uint32_t texnum, uint32_t w, uint32_t h,
  * (or a texture) changed; the other slots form a second tree, stored behind the first, that every
  * commit rebuilds -- a commit after changing only non-static slots rewrites just that part of the
  * device arrays.  Rays visit the second tree after the first.
- * A commit of per-frame geometry does NOT wait for the frames in flight: the device arrays hold two regions for the
+ * A commit of per-frame geometry does NOT wait for the frames in flight: the device arrays hold three regions for the
  * per-frame part, the commit writes the one those frames do not read (asynchronously, from pinned staging memory, on a
- * stream of its own) and waits only for the last launch that read it, two commits ago -- the host builds the tree of
+ * stream of its own) and waits only for the last launch that read it, three commits ago -- the host builds the tree of
  * frame n + 1 while the device renders frame n.  A commit that changes static geometry or textures, the first commit,
  * one whose per-frame part outgrows its region, and per-frame geometry without any static geometry wait for the device. */
 int mq_scene_commit(mq_ctx* ctx);

@@ -119,20 +119,21 @@ struct mq_ctx {
     // regions of dyn_cap_* entries, and a commit of per-frame geometry writes the one the frames in flight do not read (asynchronously,
     // from pinned staging memory, on its own stream) -- the host builds frame n + 1's tree while the device renders frame n.
     uint32_t dyn_cap_nodes = 0, dyn_cap_tris = 0; // entries per region (0: the device arrays hold no second region)
+    static const int MQ_DYN_REGIONS = 3;          // regions of the per-frame part: a commit writes the one the last MQ_DYN_REGIONS - 1 commits did not (the host may prepare frame n + 2 while frame n renders)
     int dyn_parity = 0;                           // region the current scene (c->scene) points at
-    DevBuf d_ext_b[MQ_MAX_GEOMETRIES], d_idx_b[MQ_MAX_GEOMETRIES], d_prev_b[MQ_MAX_GEOMETRIES]; // the per-slot arrays of region 1 (region 0: d_ext / d_idx / d_prev)
-    void* stage[2] = {nullptr, nullptr}; size_t stage_bytes[2] = {0, 0}; // pinned staging memory per region
+    DevBuf d_ext_x[MQ_DYN_REGIONS - 1][MQ_MAX_GEOMETRIES], d_idx_x[MQ_DYN_REGIONS - 1][MQ_MAX_GEOMETRIES], d_prev_x[MQ_DYN_REGIONS - 1][MQ_MAX_GEOMETRIES]; // the per-slot arrays of regions 1.. (region 0: d_ext / d_idx / d_prev)
+    void* stage[MQ_DYN_REGIONS] = {}; size_t stage_bytes[MQ_DYN_REGIONS] = {}; // pinned staging memory per region
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_uploaded = nullptr; bool uploaded_valid = false;       // the last asynchronous commit has landed
-    hipEvent_t ev_scene_used[2] = {nullptr, nullptr}; bool scene_used_valid[2] = {false, false}; // last launch that read region p
-    hipStream_t scene_used_stream[2] = {nullptr, nullptr}; bool scene_used_mixed[2] = {false, false}; // (read from more than one stream: the commit falls back to a device synchronisation)
+    hipEvent_t ev_scene_used[MQ_DYN_REGIONS] = {}; bool scene_used_valid[MQ_DYN_REGIONS] = {}; // last launch that read region p
+    hipStream_t scene_used_stream[MQ_DYN_REGIONS] = {}; bool scene_used_mixed[MQ_DYN_REGIONS] = {}; // (read from more than one stream: the commit falls back to a device synchronisation)
     uint32_t commits_async = 0;
     std::vector<MqTri> flat_scratch;
     // the tree of the per-frame geometry built on the device (property "per-frame BVH"; mq_devbvh.hip)
     DevBuf d_db_scratch; uint32_t db_cap = 0;  // the builder's scratch for up to db_cap triangles
-    uint32_t* db_ctr_host[2] = {nullptr, nullptr}; // pinned copies of the builder's counters per region (node count, flags), read after the fact
-    bool db_ctr_pending[2] = {false, false};
-    bool mirror_from_device = false; uint32_t db_tris[2] = {0, 0};
+    uint32_t* db_ctr_host[MQ_DYN_REGIONS] = {}; // pinned copies of the builder's counters per region (node count, flags), read after the fact
+    bool db_ctr_pending[MQ_DYN_REGIONS] = {};
+    bool mirror_from_device = false; uint32_t db_tris[MQ_DYN_REGIONS] = {};
     uint32_t commits_device = 0;
     std::vector<MqNode> pend_nodes; std::vector<MqTri> pend_tris; std::vector<MqLeafRec> pend_leaves; bool mirror_pending = false; // per-frame trees of the last asynchronous commit, not yet in nodes / tris / leaves
     uint32_t n_dyn_nodes = 0, n_dyn_tris = 0, n_dyn_leaves = 0;
@@ -471,7 +472,7 @@ void free_frame_state(mq_ctx* c) {
 }
 void free_scene_dev(mq_ctx* c) {
     dev_free(c->d_nodes); dev_free(c->d_tris); dev_free(c->d_leaves); dev_free(c->d_shade); dev_free(c->d_texdesc); dev_free(c->d_texels);
-    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); dev_free(c->d_ext_b[s]); dev_free(c->d_idx_b[s]); dev_free(c->d_prev_b[s]); }
+    for (int s = 0; s < MQ_MAX_GEOMETRIES; s++) { dev_free(c->d_ext[s]); dev_free(c->d_idx[s]); dev_free(c->d_prev[s]); for (int k = 0; k < mq_ctx::MQ_DYN_REGIONS - 1; k++) { dev_free(c->d_ext_x[k][s]); dev_free(c->d_idx_x[k][s]); dev_free(c->d_prev_x[k][s]); } }
     c->dyn_cap_nodes = c->dyn_cap_tris = 0; c->dyn_parity = 0;
 }
 
@@ -584,7 +585,7 @@ void mq_destroy(mq_ctx* c) {
         if (c->ev_bounced) (void)hipEventDestroy(c->ev_bounced);
         if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
         if (c->ev_uploaded) (void)hipEventDestroy(c->ev_uploaded);
-        for (int k = 0; k < 2; k++) { if (c->ev_scene_used[k]) (void)hipEventDestroy(c->ev_scene_used[k]); if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->db_ctr_host[k]) (void)hipHostFree(c->db_ctr_host[k]); }
+        for (int k = 0; k < mq_ctx::MQ_DYN_REGIONS; k++) { if (c->ev_scene_used[k]) (void)hipEventDestroy(c->ev_scene_used[k]); if (c->stage[k]) (void)hipHostFree(c->stage[k]); if (c->db_ctr_host[k]) (void)hipHostFree(c->db_ctr_host[k]); }
         dev_free(c->d_db_scratch);
         for (auto& pr : c->ev_pt_t) for (auto& e4 : pr) if (e4) (void)hipEventDestroy(e4);
         for (int k = 0; k < mq_ctx::MAX_SUBS - 1; k++) { if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]); if (c->side[k]) (void)hipStreamDestroy(c->side[k]); }
@@ -867,7 +868,7 @@ int ensure_upload_stream(mq_ctx* c) {
         }
     }
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_uploaded, hipEventDisableTiming));
-    for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_scene_used[k], hipEventDisableTiming));
+    for (int k = 0; k < mq_ctx::MQ_DYN_REGIONS; k++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_scene_used[k], hipEventDisableTiming));
     return MQ_OK;
 }
 
@@ -880,13 +881,14 @@ int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
     if ((r = ensure_upload_stream(c))) return r;
     static const bool times = getenv("MQ_DEBUG_COMMIT_TIMES") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
-    const int p = c->dyn_parity ^ 1;
+    const int p = (c->dyn_parity + 1) % mq_ctx::MQ_DYN_REGIONS;
+    const bool had_reader = c->scene_used_valid[p] || c->scene_used_mixed[p];
     if (c->scene_used_mixed[p]) { HIPCHK(c, hipDeviceSynchronize()); }
     else if (c->scene_used_valid[p]) HIPCHK(c, hipEventSynchronize(c->ev_scene_used[p]));
     c->scene_used_valid[p] = false; c->scene_used_mixed[p] = false;
-    HIPCHK(c, hipStreamSynchronize(c->up_stream));
+    if (!had_reader) HIPCHK(c, hipStreamSynchronize(c->up_stream)); // (nobody rendered from this region since it was written: its upload -- the last reader of its staging memory -- may still be on its way)
     const auto t_1 = std::chrono::steady_clock::now();
-    for (int k = 0; k < 2; k++) if (c->db_ctr_pending[k]) { // what the last builds reported
+    for (int k = p; k == p; k++) if (c->db_ctr_pending[k]) { // what the last build into this region reported (the frames that read it have finished: so has the copy of its counters)
         c->db_ctr_pending[k] = false;
         if (c->db_ctr_host[k][MQ_DB_ERR]) return fail(c, MQ_EHIP, "the device builder of the per-frame tree flagged an overflow (flags " + std::to_string(c->db_ctr_host[k][MQ_DB_ERR]) + ")");
     }
@@ -900,7 +902,7 @@ int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
         if ((r = dev_alloc(c, c->d_db_scratch, bytes))) return r;
         c->db_cap = cap;
     }
-    for (int k = 0; k < 2; k++) if (!c->db_ctr_host[k]) HIPCHK(c, hipHostMalloc((void**)&c->db_ctr_host[k], MQ_DB_WORDS * 4, hipHostMallocDefault));
+    for (int k = 0; k < mq_ctx::MQ_DYN_REGIONS; k++) if (!c->db_ctr_host[k]) HIPCHK(c, hipHostMalloc((void**)&c->db_ctr_host[k], MQ_DB_WORDS * 4, hipHostMallocDefault));
     size_t need = al(td * sizeof(MqTri));
     for (int sl = 0; sl < MQ_MAX_GEOMETRIES; sl++) {
         const MqHostGeo& g = c->geo[sl];
@@ -937,7 +939,7 @@ int commit_per_frame_on_device(mq_ctx* c, const std::vector<MqTri>& flat) {
         if (g.flags & MQ_GEO_STATIC) continue;
         c->scene.geo[sl].ext = nullptr; c->scene.geo[sl].idx = nullptr; c->scene.geo[sl].prev_vtx = nullptr;
         if (!g.n_tri()) continue;
-        DevBuf& be = p ? c->d_ext_b[sl] : c->d_ext[sl]; DevBuf& bi = p ? c->d_idx_b[sl] : c->d_idx[sl]; DevBuf& bp = p ? c->d_prev_b[sl] : c->d_prev[sl];
+        DevBuf& be = p ? c->d_ext_x[p - 1][sl] : c->d_ext[sl]; DevBuf& bi = p ? c->d_idx_x[p - 1][sl] : c->d_idx[sl]; DevBuf& bp = p ? c->d_prev_x[p - 1][sl] : c->d_prev[sl];
         auto room = [&](DevBuf& b, size_t bytes) -> int { return (!b.p || b.bytes < bytes) ? dev_alloc(c, b, bytes + bytes / 2 + 4096) : MQ_OK; };
         if ((r = room(be, g.ext.size() * sizeof(mq_ext)))) return r;
         if ((r = push(be.p, g.ext.data(), g.ext.size() * sizeof(mq_ext)))) return r;
@@ -1031,17 +1033,18 @@ int mq_scene_commit(mq_ctx* c) {
     static const bool force_sync = getenv("MQ_DEBUG_COMMIT_SYNC") != nullptr; // the A/B switch: wait for the device, write in place (round 2's commit)
     const bool fits = c->dyn_cap_tris != 0 && nd <= c->dyn_cap_nodes && td <= c->dyn_cap_tris && ld <= c->dyn_cap_tris;
     if (partial && ns != 0 && fits && !force_sync) {
-        const int p = c->dyn_parity ^ 1;
+        const int p = (c->dyn_parity + 1) % mq_ctx::MQ_DYN_REGIONS;
         if ((r = ensure_upload_stream(c))) return r;
         static const bool times = getenv("MQ_DEBUG_COMMIT_TIMES") != nullptr;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         const auto t_a = now();
+        const bool had_reader = c->scene_used_valid[p] || c->scene_used_mixed[p];
         if (c->scene_used_mixed[p]) { HIPCHK(c, hipDeviceSynchronize()); }
         else if (c->scene_used_valid[p]) HIPCHK(c, hipEventSynchronize(c->ev_scene_used[p]));
         c->scene_used_valid[p] = false; c->scene_used_mixed[p] = false;
         const auto t_b = now();
-        HIPCHK(c, hipStreamSynchronize(c->up_stream)); // (the staging memory of region p was last read by the copies of two commits ago: long done)
+        if (!had_reader) HIPCHK(c, hipStreamSynchronize(c->up_stream)); // (nobody rendered from this region since it was written: its upload, the last reader of its staging memory, may still be on its way)
         const auto t_c = now();
         const size_t on = ns + (size_t)p * c->dyn_cap_nodes, ot = ts + (size_t)p * c->dyn_cap_tris, ol = ls + (size_t)p * c->dyn_cap_tris; // where region p starts
         // staging layout: nodes | tris | leaves | shading records | per-slot arrays, each 256-byte aligned
@@ -1082,7 +1085,7 @@ int mq_scene_commit(mq_ctx* c) {
             if (g.flags & MQ_GEO_STATIC) continue;
             c->scene.geo[sl].ext = nullptr; c->scene.geo[sl].idx = nullptr; c->scene.geo[sl].prev_vtx = nullptr;
             if (!g.n_tri()) continue;
-            DevBuf& be = p ? c->d_ext_b[sl] : c->d_ext[sl]; DevBuf& bi = p ? c->d_idx_b[sl] : c->d_idx[sl]; DevBuf& bp = p ? c->d_prev_b[sl] : c->d_prev[sl];
+            DevBuf& be = p ? c->d_ext_x[p - 1][sl] : c->d_ext[sl]; DevBuf& bi = p ? c->d_idx_x[p - 1][sl] : c->d_idx[sl]; DevBuf& bp = p ? c->d_prev_x[p - 1][sl] : c->d_prev[sl];
             auto room = [&](DevBuf& b, size_t bytes) -> int { return (!b.p || b.bytes < bytes) ? dev_alloc(c, b, bytes + bytes / 2 + 4096) : MQ_OK; };
             if ((r = room(be, g.ext.size() * sizeof(mq_ext)))) return r;
             if ((r = push(be.p, g.ext.data(), g.ext.size() * sizeof(mq_ext)))) return r;
@@ -1106,7 +1109,7 @@ int mq_scene_commit(mq_ctx* c) {
     }
     mirror();
     HIPCHK(c, hipDeviceSynchronize());
-    if (c->up_stream) { c->scene_used_valid[0] = c->scene_used_valid[1] = false; c->scene_used_mixed[0] = c->scene_used_mixed[1] = false; }
+    if (c->up_stream) for (int k = 0; k < mq_ctx::MQ_DYN_REGIONS; k++) { c->scene_used_valid[k] = false; c->scene_used_mixed[k] = false; c->db_ctr_pending[k] = false; }
     if (partial && (ns == 0 || (force_sync && fits)) && c->dyn_parity == 0 && c->d_nodes.bytes >= c->nodes.size() * sizeof(MqNode) && c->d_tris.bytes >= c->tris.size() * sizeof(MqTri) && c->d_shade.bytes >= c->tris.size() * sizeof(MqShadeRec)
         && c->d_leaves.bytes >= c->leaves.size() * sizeof(MqLeafRec)) { // per-frame geometry without a static tree: in place, behind a synchronisation
         std::vector<MqShadeRec> recs;
@@ -1127,12 +1130,12 @@ int mq_scene_commit(mq_ctx* c) {
     // two regions for the per-frame part (see above), each with room to grow without another full upload; the first holds the
     // part committed now, right behind the static part -- the layout of the host mirror
     const size_t cap_tris = td + 16384, cap_nodes = std::max(nd + 8192, c->props.dyn_bvh ? cap_tris : (size_t)0); // (a device-built tree may have as many nodes as triangles)
-    if ((r = dev_alloc(c, c->d_nodes, (ns + 2 * cap_nodes) * sizeof(MqNode)))) return r;
-    if ((r = dev_alloc(c, c->d_tris, (ts + 2 * cap_tris) * sizeof(MqTri)))) return r;
-    if ((r = dev_alloc(c, c->d_leaves, (ls + 2 * cap_tris) * sizeof(MqLeafRec)))) return r; // (at most one record per triangle: a region holds cap_tris records)
+    if ((r = dev_alloc(c, c->d_nodes, (ns + mq_ctx::MQ_DYN_REGIONS * cap_nodes) * sizeof(MqNode)))) return r;
+    if ((r = dev_alloc(c, c->d_tris, (ts + mq_ctx::MQ_DYN_REGIONS * cap_tris) * sizeof(MqTri)))) return r;
+    if ((r = dev_alloc(c, c->d_leaves, (ls + mq_ctx::MQ_DYN_REGIONS * cap_tris) * sizeof(MqLeafRec)))) return r; // (at most one record per triangle: a region holds cap_tris records)
     if (!c->leaves.empty()) HIPCHK(c, hipMemcpy(c->d_leaves.p, c->leaves.data(), c->leaves.size() * sizeof(MqLeafRec), hipMemcpyHostToDevice));
     c->dyn_cap_nodes = (uint32_t)cap_nodes; c->dyn_cap_tris = (uint32_t)cap_tris; c->dyn_parity = 0;
-    if ((r = dev_alloc(c, c->d_shade, (ts + 2 * cap_tris) * sizeof(MqShadeRec)))) return r;
+    if ((r = dev_alloc(c, c->d_shade, (ts + mq_ctx::MQ_DYN_REGIONS * cap_tris) * sizeof(MqShadeRec)))) return r;
     if (!c->nodes.empty()) HIPCHK(c, hipMemcpy(c->d_nodes.p, c->nodes.data(), c->nodes.size() * sizeof(MqNode), hipMemcpyHostToDevice));
     if (!c->tris.empty()) HIPCHK(c, hipMemcpy(c->d_tris.p, c->tris.data(), c->tris.size() * sizeof(MqTri), hipMemcpyHostToDevice));
     if ((r = upload_slot_arrays(c, true))) return r;
